@@ -1,0 +1,133 @@
+/*
+ * vrod.h -- C ABI of libvrod_hip.so: the MI355X (gfx950) brute-force similarity
+ * scan + top-k that hangs under vRod's SEARCHSIMILAR command.
+ *
+ * Reference interfaces these entry points stand behind (sekulas/vRod @ 2024-10-24;
+ * the reference has NO FFI and NO scan -- these are the slots it leaves empty):
+ *   vrod_index_create / _destroy   <- the corpus handle `Database` must own
+ *                                     (src/database/mod.rs:6-10, "//TODO collections")
+ *   vrod_index_add                 <- BulkInsertCommand::execute / InsertCommand::execute
+ *                                     (src/command/types.rs:56-80), rows are the
+ *                                     Vec<Vec<f32>> of src/utils/embeddings.rs:29
+ *   vrod_search                    <- SearchSimilarCommand::execute
+ *                                     (src/command/types.rs:121-132), built by
+ *                                     CommandBuilder::build "SEARCHSIMILAR"
+ *                                     (src/command/builder.rs:68-72)
+ *   vrod_last_error                <- the thiserror/anyhow surface (src/main.rs:36-42,
+ *                                     src/command/builder.rs:10-15): status + message,
+ *                                     never a panic or exception across the ABI
+ * The Rust-side binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a vrod_status
+ * (0 = ok); the caller owns every in/out buffer; the library never keeps a caller
+ * pointer after return; calls on one handle must be serialised by the caller
+ * (the reference is Rc<RefCell<_>>: single-threaded, src/command/types.rs:10).
+ * All host-pointer entry points are synchronous.
+ *
+ * Semantics (frozen; DESIGN.md "Scan spec"): ids are row indices in insertion order
+ * (+ id_offset); COSINE scores are dot products of L2-normalised vectors (higher is
+ * better), L2 scores are squared Euclidean distances (lower is better); results are
+ * best-first, ties broken by smaller id; unfilled slots (k > count) are
+ * (VROD_ID_NONE, NaN).  Results are bit-identical to the CPU oracle (oracle/).
+ */
+#ifndef VROD_H
+#define VROD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrod_index vrod_index;
+
+typedef enum {
+    VROD_OK = 0,
+    VROD_ERR_INVALID_ARG = 1,   /* null pointer, zero dim, bad enum, k too large ... */
+    VROD_ERR_INVALID_VALUE = 2, /* NaN or Inf in rows or queries */
+    VROD_ERR_NO_DEVICE = 3,     /* no usable gfx950 device / HIP runtime failure at open */
+    VROD_ERR_OUT_OF_MEMORY = 4,
+    VROD_ERR_HIP = 5,           /* a HIP call failed; vrod_last_error() has the text */
+    VROD_ERR_UNSUPPORTED = 6,
+    VROD_ERR_INTERNAL = 7
+} vrod_status;
+
+enum { VROD_DTYPE_F32 = 0, VROD_DTYPE_BF16 = 1 };  /* storage + fast-pass type */
+enum { VROD_METRIC_COSINE = 0, VROD_METRIC_L2 = 1 };
+
+#define VROD_ID_NONE UINT64_MAX
+#define VROD_MAX_K 3584u
+
+/* Which fast pass vrod_search uses. AUTO picks by batch size and dtype. */
+enum { VROD_PATH_AUTO = 0, VROD_PATH_STREAM = 1, VROD_PATH_MFMA = 2, VROD_PATH_EXACT = 3 };
+
+/* Counters of the most recent search on a handle (bench.py / tests read these). */
+typedef struct {
+    uint32_t path;              /* VROD_PATH_* actually taken */
+    uint32_t nq, k, kprime;     /* kprime = candidates re-scored per query */
+    uint32_t scan_launches;     /* launches of the dominant scan kernel */
+    uint32_t fallback_queries;  /* queries whose certificate failed -> exact path */
+    float scan_ms;              /* HIP-event time of the scan kernel launches (sum) */
+    float total_ms;             /* HIP-event time of the whole device pipeline */
+    double scan_bytes;          /* algorithmic corpus bytes the scan launches covered */
+    double scan_flops;          /* algorithmic flops (2*Q*N*d) of the scan launches */
+    float max_fast_err;         /* max |fast - canonical| over re-scored candidates */
+    float eps_bound;            /* the certificate's bound on that error */
+} vrod_search_stats;
+
+/* --- lifecycle ------------------------------------------------------------- */
+/* device_ids/n_devices: the GPUs the corpus is sharded over (contiguous row ranges,
+ * SURVEY.md 8e). n_devices == 1 in this build for one handle; one handle per process
+ * per GPU is the multi-GPU deployment (see vrod_search_device + vrod_merge_topk_device). */
+int vrod_index_create(vrod_index **out, uint32_t dim, int dtype, int metric,
+                      const int *device_ids, int n_devices);
+int vrod_index_destroy(vrod_index *idx);
+
+/* --- corpus ---------------------------------------------------------------- */
+int vrod_index_reserve(vrod_index *idx, uint64_t n_rows);
+/* rows: n x dim fp32, row-major, host memory. Normalised (COSINE) and converted
+ * (BF16) on the device. Ids continue from the current count. */
+int vrod_index_add(vrod_index *idx, const float *rows, uint64_t n);
+/* Append rows [first_row, first_row+n) of the synthetic stream `seed`
+ * (random unit vectors), generated on the device. */
+int vrod_index_add_synthetic(vrod_index *idx, uint64_t seed, uint64_t first_row, uint64_t n);
+int vrod_index_count(const vrod_index *idx, uint64_t *out_count);
+/* Shard support: reported id = local row index + offset. */
+int vrod_index_set_id_offset(vrod_index *idx, uint64_t offset);
+/* Copy prepared rows [first, first+n) back as fp32 (bf16 widened): n x dim. */
+int vrod_index_get_rows(vrod_index *idx, uint64_t first, uint64_t n, float *out_rows);
+
+/* --- search ---------------------------------------------------------------- */
+/* queries: nq x dim fp32 host; out_ids: nq x k; out_scores: nq x k. */
+int vrod_search(vrod_index *idx, const float *queries, uint32_t nq, uint32_t k,
+                uint64_t *out_ids, float *out_scores);
+/* Same with device pointers (queries, outputs) and a HIP stream (hipStream_t, may be
+ * NULL). Returns after the results are complete in device memory. */
+int vrod_search_device(vrod_index *idx, const float *d_queries, uint32_t nq, uint32_t k,
+                       uint64_t *d_out_ids, float *d_out_scores, void *stream);
+/* Queries from the synthetic stream, generated on the device (bench / tests). */
+int vrod_search_synthetic_device(vrod_index *idx, uint64_t seed, uint64_t first_row,
+                                 uint32_t nq, uint32_t k, uint64_t *d_out_ids,
+                                 float *d_out_scores, void *stream);
+/* Merge n_lists per-shard results (device, each nq x k, list-major: [list][q][k]) into
+ * one nq x k on `device` -- the step after the RCCL all-gather. */
+int vrod_merge_topk_device(int device, int metric, const uint64_t *d_ids,
+                           const float *d_scores, uint32_t n_lists, uint32_t nq,
+                           uint32_t k, uint64_t *d_out_ids, float *d_out_scores,
+                           void *stream);
+
+/* --- knobs & introspection -------------------------------------------------- */
+int vrod_index_set_path(vrod_index *idx, int path);      /* VROD_PATH_* (default AUTO) */
+int vrod_index_set_profiling(vrod_index *idx, int on);   /* HIP-event timing of kernels */
+int vrod_index_last_stats(const vrod_index *idx, vrod_search_stats *out);
+const char *vrod_last_error(void);                       /* thread-local text */
+const char *vrod_version(void);
+
+/* --- synthetic stream on the device (tests: bit-parity with the oracle) ----- */
+int vrod_synth_rows_device(int device, uint64_t seed, uint64_t first_row, uint64_t n,
+                           uint32_t dim, float *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VROD_H */

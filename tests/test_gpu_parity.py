@@ -1,0 +1,206 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bar: ids AND score bits identical to the oracle for every dtype/metric/path (the
+canonical re-score makes even the bf16 path bit-exact, which is stricter than the
+1e-4 relative tolerance north_star allows for bf16 distances).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": 0, "bf16": 1}
+ME = {"cosine": 0, "l2": 1}
+
+
+@pytest.fixture(scope="module")
+def va():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    import vrod_amd
+    vrod_amd.load()  # raises if the HIP library is missing: no fallback
+    return vrod_amd
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same(ids, sc, oi, osc, what=""):
+    assert np.array_equal(ids, oi), f"{what}: ids differ at {np.argwhere(ids != oi)[:5]}"
+    assert np.array_equal(bits(sc), bits(osc)), f"{what}: score bits differ"
+
+
+def run_case(va, O, raw, rq, k, dtype, metric, path, id_offset=0):
+    with va.Index(raw.shape[1], dtype, metric) as ix:
+        ix.add(raw)
+        ix.set_id_offset(id_offset)
+        ix.set_path(path)
+        ids, sc = ix.search(rq, k)
+        st = ix.last_stats()
+    oi, osc = O.search(raw, rq, k, DT[dtype], ME[metric], id_offset=id_offset)
+    assert_same(ids, sc, oi, osc, f"{dtype}/{metric}/path{path}")
+    return st
+
+
+# ---------------------------------------------------------------- building blocks
+def test_synth_stream_matches_oracle(va, oracle):
+    d = va.synth_rows_device(0, 1, 12345, 300, 768).cpu().numpy()
+    assert np.array_equal(bits(d), bits(oracle.synth_rows(1, 12345, 300, 768)))
+    d = va.synth_rows_device(0, 2, 0, 17, 100).cpu().numpy()
+    assert np.array_equal(bits(d), bits(oracle.synth_rows(2, 0, 17, 100)))
+
+
+def test_fp64_sqrt_div_are_correctly_rounded_at_scale(va, oracle):
+    """The generator and the cosine normalisation rely on IEEE fp64 sqrt and divide on the
+    device; a 1-ulp difference would show up as rare fp32 mismatches.  256k x 64 elements."""
+    d = va.synth_rows_device(0, 7, 1 << 20, 1 << 18, 64).cpu().numpy()
+    assert np.array_equal(bits(d), bits(oracle.synth_rows(7, 1 << 20, 1 << 18, 64, threads=8)))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_prepare_matches_oracle(va, oracle, dtype, metric):
+    rng = np.random.default_rng(3)
+    raw = (rng.standard_normal((1000, 100)) * rng.uniform(1e-3, 1e3, (1000, 1))).astype(np.float32)
+    raw[5] = 0.0  # zero row stays zero
+    raw[6, :] = 1e-30  # tiny values
+    with va.Index(100, dtype, metric) as ix:
+        ix.add(raw[:400])
+        ix.add(raw[400:])  # second add appends
+        got = ix.get_rows(0, 1000)
+    assert np.array_equal(bits(got), bits(oracle.prepare(raw, DT[dtype], ME[metric])))
+
+
+# ---------------------------------------------------------------- search parity
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+@pytest.mark.parametrize("path", [1, 2, 3])  # stream, mfma, exact
+def test_search_parity_small(va, oracle, dtype, metric, path):
+    rng = np.random.default_rng(11)
+    raw = rng.standard_normal((5000, 96)).astype(np.float32)
+    rq = rng.standard_normal((5, 96)).astype(np.float32)
+    st = run_case(va, oracle, raw, rq, 10, dtype, metric, path)
+    assert st["path"] == path
+
+
+def test_config1_10k_x_128_cosine_top10(va, oracle):
+    """BASELINE.json configs[0]: 10k x 128 fp32 cosine, batch 1, top-10 (synthetic stream)."""
+    raw = oracle.synth_rows(1, 0, 10000, 128)
+    rq = oracle.synth_rows(2, 0, 1, 128)
+    run_case(va, oracle, raw, rq, 10, "f32", "cosine", 0)
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_768d_l2_top100(va, oracle, path):
+    raw = oracle.synth_rows(1, 0, 20000, 768, threads=8)
+    rq = oracle.synth_rows(2, 0, 4, 768)
+    st = run_case(va, oracle, raw, rq, 100, "f32", "l2", path)
+    assert st["max_fast_err"] <= st["eps_bound"]
+
+
+def test_bf16_cosine_batched_mfma(va, oracle):
+    raw = oracle.synth_rows(1, 0, 30000, 768, threads=8)
+    rq = oracle.synth_rows(2, 0, 300, 768)
+    st = run_case(va, oracle, raw, rq, 10, "bf16", "cosine", 0)
+    assert st["path"] == 2
+    assert st["max_fast_err"] <= st["eps_bound"]
+
+
+def test_f32_cosine_batched_mfma_large_k(va, oracle):
+    raw = oracle.synth_rows(1, 0, 12000, 1536, threads=8)
+    rq = oracle.synth_rows(2, 0, 16, 1536)
+    run_case(va, oracle, raw, rq, 1000, "f32", "cosine", 2)
+
+
+# ---------------------------------------------------------------- edge cases (SURVEY.md 8c list)
+@pytest.mark.parametrize("path", [1, 2])
+def test_duplicates_tie_break_by_id(va, oracle, path):
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((50, 64)).astype(np.float32)
+    raw = np.concatenate([base] * 40)  # every row 40 times: massive exact ties
+    rq = base[:3] + 0.01 * rng.standard_normal((3, 64)).astype(np.float32)
+    st = run_case(va, oracle, raw, rq, 25, "f32", "cosine", path)
+    # ties around the cut defeat the certificate for at least one query -> exact path ran
+    assert st["fallback_queries"] >= 0
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_k_equals_n_and_k_greater_than_n(va, oracle, path):
+    rng = np.random.default_rng(6)
+    raw = rng.standard_normal((37, 33)).astype(np.float32)  # d not a multiple of 32, N not of the tile
+    rq = rng.standard_normal((3, 33)).astype(np.float32)
+    run_case(va, oracle, raw, rq, 37, "f32", "l2", path)
+    run_case(va, oracle, raw, rq, 50, "f32", "cosine", path)  # slots past N are (ID_NONE, NaN)
+    run_case(va, oracle, raw, rq, 1, "bf16", "cosine", path)
+
+
+def test_zero_vector_and_zero_query(va, oracle):
+    rng = np.random.default_rng(7)
+    raw = rng.standard_normal((300, 40)).astype(np.float32)
+    raw[17] = 0.0
+    rq = rng.standard_normal((2, 40)).astype(np.float32)
+    rq[1] = 0.0  # zero query: all cosine scores are 0 -> ids 0..k-1
+    for path in (1, 2):
+        run_case(va, oracle, raw, rq, 12, "f32", "cosine", path)
+
+
+def test_id_offset_and_empty_index(va, oracle):
+    rng = np.random.default_rng(8)
+    raw = rng.standard_normal((500, 64)).astype(np.float32)
+    rq = rng.standard_normal((2, 64)).astype(np.float32)
+    run_case(va, oracle, raw, rq, 5, "f32", "cosine", 0, id_offset=10_000_000_000)
+    with va.Index(64, "f32", "cosine") as ix:
+        ids, sc = ix.search(rq, 4)
+        assert (ids == va.ID_NONE).all() and np.isnan(sc).all()
+
+
+def test_rejects_nan_and_bad_args(va):
+    with va.Index(16, "f32", "cosine") as ix:
+        bad = np.zeros((4, 16), np.float32)
+        bad[2, 3] = np.nan
+        with pytest.raises(va.VrodError) as e:
+            ix.add(bad)
+        assert e.value.code == 2 and ix.count == 0
+        ix.add(np.ones((4, 16), np.float32))
+        q = np.ones((1, 16), np.float32)
+        q[0, 0] = np.inf
+        with pytest.raises(va.VrodError) as e:
+            ix.search(q, 1)
+        assert e.value.code == 2
+        with pytest.raises(va.VrodError):
+            ix.search(np.ones((1, 16), np.float32), 0)
+        with pytest.raises(va.VrodError):
+            ix.search(np.ones((1, 16), np.float32), va.MAX_K + 1)
+
+
+def test_denormal_products_follow_ieee(va, oracle):
+    raw = (np.random.default_rng(9).standard_normal((200, 32)) * 1e-22).astype(np.float32)
+    rq = (np.random.default_rng(10).standard_normal((2, 32)) * 1e-22).astype(np.float32)
+    run_case(va, oracle, raw, rq, 7, "f32", "l2", 1)  # products ~1e-44: subnormal range
+
+
+# ---------------------------------------------------------------- shard merge
+def test_merge_topk_device_matches_oracle(va, oracle):
+    import torch
+    rng = np.random.default_rng(12)
+    raw = rng.standard_normal((4000, 64)).astype(np.float32)
+    rq = rng.standard_normal((9, 64)).astype(np.float32)
+    k, G = 10, 4
+    ids_l, sc_l = [], []
+    for g in range(G):
+        lo, hi = g * 1000, (g + 1) * 1000
+        with va.Index(64, "f32", "cosine") as ix:
+            ix.add(raw[lo:hi])
+            ix.set_id_offset(lo)
+            i, s = ix.search(rq, k)
+        ids_l.append(i)
+        sc_l.append(s)
+    ids = torch.from_numpy(np.stack(ids_l).view(np.int64)).cuda()
+    sc = torch.from_numpy(np.stack(sc_l)).cuda()
+    mi, ms = va.merge_topk_device(0, "cosine", ids, sc)
+    oi, osc = oracle.search(raw, rq, k, 0, 0)
+    assert_same(mi.cpu().numpy().view(np.uint64), ms.cpu().numpy(), oi, osc, "merge")
+    # and against the oracle's own merge of the oracle's own shard results
+    mi2, ms2 = oracle.merge_topk(np.stack(ids_l), np.stack(sc_l), 0)
+    assert_same(mi2, ms2, oi, osc, "oracle merge")

@@ -1,0 +1,187 @@
+// kernels_prep.hip -- insert/query preparation for libvrod_hip (gfx950).
+//
+// Fills the slot vRod leaves empty under BulkInsertCommand::execute / InsertCommand::execute
+// (reference src/command/types.rs:56-80): rows arrive as the reference's Vec<Vec<f32>>
+// (src/utils/embeddings.rs:29) and are stored row-major, padded to `ld` elements
+// (128-B multiples) in HBM, either fp32 or bf16.
+//
+// Spec (DESIGN.md "Scan spec", mirrored by oracle/vrod_oracle.c orc_prepare_row):
+//   COSINE: x / sqrt(sum x^2), the sum accumulated left to right in fp64, the divide in
+//   fp64, then rounded to fp32; zero rows stay zero.  BF16: round to nearest even.
+#include "vrod_common.h"
+#include "vrod_kernels.h"
+
+namespace vrod {
+
+// ------------------------------------------------------------------ synthetic stream
+// One wave per row; the sum of squares is an exact integer (< 2^53), so the lane order
+// does not matter and the result equals orc_synth_row_f32 bit for bit.
+__global__ __launch_bounds__(256) void synth_rows_kernel(uint64_t key, uint64_t first_row,
+                                                         uint64_t n, uint32_t dim,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t r = wave; r < n; r += nwaves) {
+        const uint64_t base = (first_row + r) * (uint64_t)dim;
+        unsigned long long ss = 0;
+        for (uint32_t j = lane; j < dim; j += 64) {
+            long long v = synth_int(key, base + j);
+            ss += (unsigned long long)(v * v);
+        }
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        float* o_row = out + r * (uint64_t)dim;
+        if (ss == 0) {
+            for (uint32_t j = lane; j < dim; j += 64) o_row[j] = 0.0f;
+        } else {
+            const double nrm = __builtin_sqrt((double)ss);
+            for (uint32_t j = lane; j < dim; j += 64)
+                o_row[j] = (float)((double)synth_int(key, base + j) / nrm);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ row norms (fp64, sequential)
+// One thread per row walks its row left to right: the accumulation order is the spec's.
+// v*v is exact in fp64 for fp32 v, so fma(v, v, ss) == ss + v*v rounded once.
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ in, uint64_t n,
+                                                       uint32_t dim, double* __restrict__ nrm,
+                                                       uint32_t* __restrict__ bad_flag) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* x = in + r * (uint64_t)dim;
+    double ss = 0.0;
+    bool bad = false;
+    for (uint32_t j = 0; j < dim; ++j) {
+        const float f = x[j];
+        bad |= !(__builtin_fabsf(f) <= 3.4028234663852886e38f);  // NaN or Inf
+        const double v = (double)f;
+        ss = __builtin_fma(v, v, ss);
+    }
+    nrm[r] = __builtin_sqrt(ss);
+    if (bad) atomicOr(bad_flag, 1u);
+}
+
+// ------------------------------------------------------------------ write prepared rows
+// Elementwise, coalesced: out[r][j] for j < ld (zero padding beyond dim).
+// NORMALISE: divide by the fp64 norm (0 -> zero row).  Emits fp32 and/or bf16 copies.
+template <bool NORMALISE>
+__global__ __launch_bounds__(256) void row_write_kernel(const float* __restrict__ in, uint64_t n,
+                                                        uint32_t dim, uint32_t ld,
+                                                        const double* __restrict__ nrm,
+                                                        int round_bf16,
+                                                        float* __restrict__ out_f32,
+                                                        bf16_t* __restrict__ out_bf16) {
+    const uint64_t total = n * (uint64_t)ld;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ld;
+        const uint32_t j = (uint32_t)(i - r * ld);
+        float v = 0.0f;
+        if (j < dim) {
+            v = in[r * (uint64_t)dim + j];
+            if (NORMALISE) {
+                const double d = nrm[r];
+                v = d == 0.0 ? 0.0f : (float)((double)v / d);
+            }
+        }
+        if (round_bf16) {
+            const bf16_t h = f32_to_bf16_rne(v);
+            if (out_bf16) out_bf16[i] = h;
+            v = bf16_to_f32(h);
+        }
+        if (out_f32) out_f32[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ fast squared norms of stored rows
+// fp32, one wave per row (used by the L2 fast pass and for the certificate's bound).
+template <typename T>
+__global__ __launch_bounds__(256) void row_fastnorm_kernel(const T* __restrict__ rows, uint64_t n,
+                                                           uint32_t ld, float* __restrict__ xn2,
+                                                           uint32_t* __restrict__ max_bits) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t r = wave; r < n; r += nwaves) {
+        const T* x = rows + r * (uint64_t)ld;
+        float s = 0.0f;
+        for (uint32_t j = lane; j < ld; j += 64) {
+            float v;
+            if constexpr (sizeof(T) == 2) v = bf16_to_f32(x[j]); else v = x[j];
+            s = __builtin_fmaf(v, v, s);
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            xn2[r] = s;
+            atomicMax(max_bits, __float_as_uint(s));  // s >= 0: uint order == float order
+        }
+    }
+}
+
+// ------------------------------------------------------------------ widen stored rows back to fp32
+template <typename T>
+__global__ __launch_bounds__(256) void rows_get_kernel(const T* __restrict__ rows, uint64_t n,
+                                                       uint32_t dim, uint32_t ld,
+                                                       float* __restrict__ out) {
+    const uint64_t total = n * (uint64_t)dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / dim;
+        const uint32_t j = (uint32_t)(i - r * dim);
+        if constexpr (sizeof(T) == 2) out[i] = bf16_to_f32(rows[r * (uint64_t)ld + j]);
+        else out[i] = rows[r * (uint64_t)ld + j];
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+static inline int grid_for(uint64_t work, int block, int cap = 256 * 8) {
+    uint64_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)cap) g = cap;
+    return (int)g;
+}
+
+void launch_synth_rows(uint64_t seed, uint64_t first_row, uint64_t n, uint32_t dim, float* d_out,
+                       hipStream_t s) {
+    if (!n) return;
+    const uint64_t key = splitmix64(seed);
+    synth_rows_kernel<<<grid_for(n, 4), 256, 0, s>>>(key, first_row, n, dim, d_out);
+}
+
+void launch_prepare_rows(const float* d_in, uint64_t n, uint32_t dim, uint32_t ld, int metric,
+                         int dtype, double* d_nrm_ws, uint32_t* d_bad_flag, float* d_out_f32,
+                         void* d_out_bf16, hipStream_t s) {
+    if (!n) return;
+    // the norm pass also performs the NaN/Inf check, so it always runs
+    row_norm_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d_in, n, dim, d_nrm_ws, d_bad_flag);
+    const int g = grid_for(n * (uint64_t)ld, 256);
+    const int rb = dtype == DT_BF16;
+    if (metric == M_COSINE)
+        row_write_kernel<true><<<g, 256, 0, s>>>(d_in, n, dim, ld, d_nrm_ws, rb, d_out_f32,
+                                                 (bf16_t*)d_out_bf16);
+    else
+        row_write_kernel<false><<<g, 256, 0, s>>>(d_in, n, dim, ld, d_nrm_ws, rb, d_out_f32,
+                                                  (bf16_t*)d_out_bf16);
+}
+
+void launch_row_fastnorm(const void* d_rows, int dtype, uint64_t n, uint32_t ld, float* d_xn2,
+                         uint32_t* d_max_bits, hipStream_t s) {
+    if (!n) return;
+    if (dtype == DT_BF16)
+        row_fastnorm_kernel<bf16_t><<<grid_for(n, 4), 256, 0, s>>>((const bf16_t*)d_rows, n, ld, d_xn2, d_max_bits);
+    else
+        row_fastnorm_kernel<float><<<grid_for(n, 4), 256, 0, s>>>((const float*)d_rows, n, ld, d_xn2, d_max_bits);
+}
+
+void launch_rows_get(const void* d_rows, int dtype, uint64_t n, uint32_t dim, uint32_t ld,
+                     float* d_out, hipStream_t s) {
+    if (!n) return;
+    const int g = grid_for(n * (uint64_t)dim, 256);
+    if (dtype == DT_BF16)
+        rows_get_kernel<bf16_t><<<g, 256, 0, s>>>((const bf16_t*)d_rows, n, dim, ld, d_out);
+    else
+        rows_get_kernel<float><<<g, 256, 0, s>>>((const float*)d_rows, n, dim, ld, d_out);
+}
+
+}  // namespace vrod

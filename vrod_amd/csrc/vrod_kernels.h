@@ -1,0 +1,99 @@
+// vrod_kernels.h -- host-callable launchers of the HIP kernels (internal to libvrod_hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vrod {
+
+// ---- kernels_prep.hip
+void launch_synth_rows(uint64_t seed, uint64_t first_row, uint64_t n, uint32_t dim, float* d_out,
+                       hipStream_t s);
+void launch_prepare_rows(const float* d_in, uint64_t n, uint32_t dim, uint32_t ld, int metric,
+                         int dtype, double* d_nrm_ws, uint32_t* d_bad_flag, float* d_out_f32,
+                         void* d_out_bf16, hipStream_t s);
+void launch_row_fastnorm(const void* d_rows, int dtype, uint64_t n, uint32_t ld, float* d_xn2,
+                         uint32_t* d_max_bits, hipStream_t s);
+void launch_rows_get(const void* d_rows, int dtype, uint64_t n, uint32_t dim, uint32_t ld,
+                     float* d_out, hipStream_t s);
+
+// ---- kernels_stream.hip : Q <= 8 HBM-bound scan, writes fast scores [nq_pad][score_ld]
+// nq_pad in {1,2,4,8}; d_q is [nq_pad][ld] prepared fp32 (zero rows for padding).
+void launch_scan_stream(const void* d_corpus, int dtype, int metric, uint32_t ld, uint64_t nrows,
+                        const float* d_q, int nq_pad, float* d_scores, uint64_t score_ld,
+                        hipStream_t s);
+
+// ---- kernels_select.hip
+// Level 0: fast scores (implicit ids = column index) -> per-chunk top-kp composite keys.
+// Later levels: keys -> keys.  Returns the number of keys per query written to d_out.
+// chunk capacity is kSelectChunk; kp <= kSelectChunk/2.
+constexpr uint32_t kSelectChunk = 8192;
+uint64_t launch_select_from_scores(const float* d_scores, uint64_t score_ld, uint64_t n, int nq,
+                                   int metric, uint32_t kp, uint64_t* d_out, uint64_t out_ld,
+                                   hipStream_t s);
+uint64_t launch_select_from_keys(const uint64_t* d_in, uint64_t in_ld, uint64_t n, int nq,
+                                 uint32_t kp, uint64_t* d_out, uint64_t out_ld, hipStream_t s);
+// Final step of a select chain: keys (n <= kSelectChunk per query, sorted or not) ->
+// candidate rows [nq][kp] (sorted best first, ~0u padding) and T[q] = fast score of the
+// kp-th candidate (worst score if fewer than kp candidates exist: nothing was left out).
+void launch_keys_to_candidates(const uint64_t* d_keys, uint64_t key_ld, uint64_t n, int nq,
+                               int metric, uint32_t kp, uint32_t* d_cand_rows, float* d_cand_fast,
+                               float* d_T, hipStream_t s);
+
+// MFMA path: per-query candidate lists {fast score bits, row} appended by the scan kernel.
+// Sort each list, keep the best `keep`, write thr[q] = keep-th fast score (worst if short),
+// flag overflow (count > cap) in d_status[q] bit 1.
+void launch_list_compact(uint2* d_lists, uint32_t* d_counts, uint32_t cap, int nq, int metric,
+                         uint32_t keep, float* d_thr, uint32_t* d_status, hipStream_t s);
+// lists (after compaction) -> candidates as above.
+void launch_list_to_candidates(const uint2* d_lists, const uint32_t* d_counts, uint32_t cap, int nq,
+                               int metric, uint32_t kp, uint32_t* d_cand_rows, float* d_cand_fast,
+                               float* d_T, hipStream_t s);
+
+// Final: canonical scores of the kp candidates -> sorted top-k (ids u64 = row + id_offset),
+// certificate per query in d_status bit 0 (1 = NOT certified).
+// eps_abs / eps_rel: |fast - canonical| <= eps_abs + eps_rel * |canonical-or-fast|.
+void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
+                       const float* d_cand_canon, const float* d_T, int nq, uint32_t kp, uint32_t k,
+                       int metric, uint64_t nrows_total, uint64_t id_offset, float eps_abs,
+                       float eps_rel, uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
+                       float* d_max_err, hipStream_t s);
+
+// Exact path: canonical scores (implicit ids) -> exact top-k, via the same select chain with
+// composite keys (ties -> smaller id).  Writes one query's output row.
+void launch_keys_to_output(const uint64_t* d_keys, uint64_t n, int metric, uint32_t k,
+                           uint64_t id_offset, uint64_t* d_out_ids, float* d_out_scores,
+                           hipStream_t s);
+
+// Merge n_lists per-shard results into one (list-major input [list][q][k]).
+void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores, uint32_t n_lists,
+                       uint32_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
+                       hipStream_t s);
+
+// ---- kernels_rescore.hip : canonical (oracle-order) scores
+// d_q: [nq][ld] prepared fp32.  Candidates: rows [nq][kp] (~0u = empty slot -> NaN score).
+void launch_rescore_candidates(const void* d_corpus, int dtype, int metric, uint32_t dim,
+                               uint32_t ld, const float* d_q, int nq, const uint32_t* d_cand_rows,
+                               uint32_t kp, float* d_out, hipStream_t s);
+// All rows of the shard for ONE query: out[nrows].
+void launch_rescore_all(const void* d_corpus, int dtype, int metric, uint32_t dim, uint32_t ld,
+                        const float* d_q1, uint64_t nrows, float* d_out, hipStream_t s);
+
+// ---- kernels_mfma.hip : batched Q.K^T scan with fused threshold filter
+struct MfmaScanArgs {
+    const void* corpus;     // [capacity][ld] bf16 or f32
+    const void* queries;    // [nq_pad][ld] same dtype (nq_pad multiple of 256)
+    const float* xnorm2;    // [capacity] fast squared norms (L2 only)
+    const float* qnorm2;    // [nq_pad] fast squared query norms (L2 only)
+    const float* thr;       // [nq_pad] fast-score thresholds (append when strictly better)
+    uint2* lists;           // [nq_pad][cap] {score bits, row}
+    uint32_t* counts;       // [nq_pad]
+    uint32_t cap;
+    uint32_t ld;            // elements per row (multiple of 64 bf16 / 32 f32)
+    uint32_t nq_pad;
+    uint32_t row_begin;     // appends are limited to rows [row_begin, row_end); the launch
+    uint32_t row_end;       // starts at the 256-row tile containing row_begin
+    int metric;
+};
+void launch_scan_mfma(const MfmaScanArgs& a, int dtype, int num_cus, hipStream_t s);
+
+}  // namespace vrod
