@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py -- the driver's measurement contract for the vRod similarity-scan hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of queries through the whole search (fast scan -> candidates ->
+canonical re-score -> certified top-k), corpus resident in HBM before the timed region.
+Default workload = the configuration BASELINE.json's metric is quoted on:
+10M x 768 bf16 cosine, batch 1024, top-10 ("cfg3").  With N GPUs the 10M rows are sharded
+into contiguous ranges (strong scaling), every rank scans its shard for the same batch and
+the per-shard top-k are all-gathered over RCCL and merged.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded by the
+library on its own stream around every launch of the dominant scan kernel; `cpu_baseline`
+is the CPU oracle (a build-authored restatement: vRod itself has no scan) timed on this
+host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: rows, dim, dtype, metric, batch, k, roofline bound
+    "cfg3": dict(n=10_000_000, dim=768, dtype="bf16", metric="cosine", nq=1024, k=10, bound="mfma"),
+    "cfg2": dict(n=1_000_000, dim=768, dtype="f32", metric="l2", nq=1, k=100, bound="hbm"),
+    "cfg4": dict(n=40_000_000, dim=768, dtype="bf16", metric="cosine", nq=1024, k=10, bound="mfma"),
+    "cfg5": dict(n=10_000_000, dim=1536, dtype="f32", metric="cosine", nq=256, k=1000, bound="mfma"),
+    "tiny": dict(n=200_000, dim=768, dtype="bf16", metric="cosine", nq=1024, k=10, bound="mfma"),
+}
+PEAK = {  # /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+    "hbm": (8000.0, "GB/s"),            # HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+    "mfma_bf16": (2500.0, "TFLOP/s"),   # dense bf16 MFMA
+    "mfma_f32": (157.3, "TFLOP/s"),     # fp32-input MFMA
+}
+CORPUS_SEED, QUERY_SEED = 1, 2
+DT = {"f32": 0, "bf16": 1}
+ME = {"cosine": 0, "l2": 1}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="override total corpus rows (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true", help="skip the extra 1-query HBM-roofline probe (cfg2)")
+    return ap.parse_args()
+
+
+def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev):
+    """Run `steps` batches; returns accumulated library stats of this rank."""
+    from vrod_amd.shard import all_gather_topk
+    nq, k = wl["nq"], wl["k"]
+    oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    osc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    if world > 1:
+        gi = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
+        gs = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
+        mi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, total_ms=0.0, max_err=0.0, eps=0.0)
+    for s in range(steps):
+        ix.search_synthetic_device(QUERY_SEED, (first_step + s) * nq, nq, k, oi, osc)
+        st = ix.last_stats()
+        if world > 1:
+            # per-shard top-k -> every rank (RCCL all-gather over xGMI), then the exact merge
+            all_gather_topk(dist, oi, osc, gi, gs)
+            va.merge_topk_device(dev.index, wl["metric"], gi, gs, mi, ms)
+        acc["scan_ms"] += st["scan_ms"]
+        acc["scan_flops"] += st["scan_flops"]
+        acc["scan_bytes"] += st["scan_bytes"]
+        acc["launches"] += st["scan_launches"]
+        acc["fallback"] += st["fallback_queries"]
+        acc["total_ms"] += st["total_ms"]
+        acc["max_err"] = max(acc["max_err"], st["max_fast_err"])
+        acc["eps"] = st["eps_bound"]
+    final = (mi, ms) if world > 1 else (oi, osc)
+    return acc, final
+
+
+def cpu_baseline(wl, va, torch, dev, n_total):
+    """Oracle on this host's cores on a bounded sample; also recall@k of the HIP path on it."""
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    dim, k = wl["dim"], wl["k"]
+    ns = int(min(n_total, max(65536, (6 << 30) // (dim * 4))))          # <= 6 GB of fp32 rows
+    ns = min(ns, 2_000_000)
+    t = time.time()
+    raw = O.synth_rows(CORPUS_SEED, 0, ns, dim, threads=cores)
+    corpus = O.prepare(raw, DT[wl["dtype"]], ME[wl["metric"]], threads=cores)
+    del raw
+    # size the query samples for ~10 s (all cores) and ~6 s (one thread) at ~1e9 mul-add/s/thread
+    q_all = int(max(2, min(64, 10.0 * 1e9 * cores / (ns * dim))))
+    q_one = int(max(1, min(8, 6.0 * 1e9 / (ns * dim))))
+    rq = O.synth_rows(QUERY_SEED, 0, q_all, dim)
+    pq = O.prepare(rq, DT[wl["dtype"]], ME[wl["metric"]])
+    gen_s = time.time() - t
+    t = time.time()
+    oi, osc = O.scan_topk(corpus, pq, k, ME[wl["metric"]], threads=cores)
+    t_all = time.time() - t
+    t = time.time()
+    O.scan_topk(corpus, pq[:q_one], k, ME[wl["metric"]], threads=1)
+    t_one = time.time() - t
+    scale = ns / float(n_total)  # scan time is linear in rows
+    out = {
+        "value": round(q_all / t_all * scale, 4), "unit": "queries/s", "cores": cores, "kind": "port",
+        "sample": f"{q_all} queries x first {ns} of {n_total} rows, {cores} threads, {t_all:.2f}s; "
+                  f"rate scaled by rows ({ns}/{n_total}); build-authored CPU restatement (vRod has no scan)",
+        "value_1thread": round(q_one / t_one * scale, 4),
+        "sample_1thread": f"{q_one} queries x {ns} rows, 1 thread (vRod is single-threaded: Rc<RefCell>), {t_one:.2f}s",
+        "host_prep_s": round(gen_s, 2),
+    }
+    # recall@k of the HIP path against the oracle on the same sample corpus / queries
+    with va.Index(dim, wl["dtype"], wl["metric"], device=dev.index) as sx:
+        sx.add_synthetic(CORPUS_SEED, 0, ns)
+        if wl["nq"] > 8:
+            sx.set_path(va.PATH_MFMA)
+        ids, sc = sx.search(rq, k)
+    hits = sum(len(set(ids[i].tolist()) & set(oi[i].tolist())) for i in range(q_all))
+    recall = hits / float(q_all * min(k, ns))
+    bit_exact = bool(np.array_equal(ids, oi) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32)))
+    return out, recall, bit_exact, f"{q_all} queries vs oracle on the first {ns} rows"
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import vrod_amd as va
+    va.load()  # raises without the HIP library: there is no fallback path
+    from vrod_amd.shard import shard_range
+
+    wl = dict(WORKLOADS[args.workload])
+    n_total = args.rows or wl["n"]
+    lo, hi = shard_range(n_total, rank, world)
+    ix = va.Index(wl["dim"], wl["dtype"], wl["metric"], device=local_rank)
+    ix.add_synthetic(CORPUS_SEED, lo, hi - lo)   # shard rows [lo, hi) of the synthetic stream, generated in HBM
+    ix.set_id_offset(lo)
+    ix.set_profiling(True)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+
+    run_steps(ix, wl, args.warmup, 0, world, rank, dist, va, torch, dev)
+    fence()
+    t0 = time.perf_counter()
+    acc, final = run_steps(ix, wl, args.steps, args.warmup, world, rank, dist, va, torch, dev)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        # per-rank kernel stats: report the slowest rank's scan time, the sum of flops
+        ks = torch.tensor([acc["scan_ms"], acc["scan_flops"], acc["scan_bytes"], float(acc["fallback"])], dtype=torch.float64, device=dev)
+        kmax = ks.clone(); dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        ksum = ks.clone(); dist.all_reduce(ksum, op=dist.ReduceOp.SUM)
+        fallback_total = int(ksum[3].item())
+    else:
+        fallback_total = acc["fallback"]
+
+    if rank == 0:
+        nq = wl["nq"]
+        value = nq * args.steps / elapsed
+        # roofline of the dominant kernel on THIS rank (rank 0): algorithmic work / HIP-event time
+        if wl["bound"] == "hbm":
+            achieved = acc["scan_bytes"] / (acc["scan_ms"] * 1e-3) / 1e9 if acc["scan_ms"] else 0.0
+            peak, unit = PEAK["hbm"]
+            kernel = "scan_stream_kernel"
+            per_launch = acc["scan_bytes"] / max(acc["launches"], 1)
+            work_key = "algorithmic_bytes_per_launch"
+        else:
+            achieved = acc["scan_flops"] / (acc["scan_ms"] * 1e-3) / 1e12 if acc["scan_ms"] else 0.0
+            peak, unit = PEAK["mfma_bf16" if wl["dtype"] == "bf16" else "mfma_f32"]
+            kernel = "scan_mfma_kernel"
+            per_launch = acc["scan_flops"] / max(acc["launches"], 1)
+            work_key = "algorithmic_flops_per_launch"
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload if world == 1 else "", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm" if wl["bound"] == "hbm" else "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": kernel,
+            "launches_per_step": acc["launches"] / max(args.steps, 1),
+            "avg_launch_ms": round(acc["scan_ms"] / max(acc["launches"], 1), 4), work_key: per_launch,
+            "timing": "HIP events on the library's stream around each scan launch, timed steps only",
+        }
+        out = {
+            "metric": "queries/sec (+ recall@10 vs CPU ref), 10M x 768 cosine, batch=1024" if args.workload == "cfg3" else f"queries/sec, {args.workload}",
+            "value": round(value, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n_total} x {wl['dim']} {wl['dtype']} {wl['metric']}, batch={nq}, top-{wl['k']}",
+                       "rows_total": n_total, "rows_per_gpu": hi - lo, "dim": wl["dim"], "batch": nq, "k": wl["k"],
+                       "metric": wl["metric"], "parallelism": f"row-shard x{world}, RCCL all-gather of per-shard top-k" if world > 1 else "single GPU",
+                       "corpus_seed": CORPUS_SEED, "query_seed": QUERY_SEED},
+            "roofline": roofline,
+            "exactness": {"certificate_fallback_queries": fallback_total, "max_fast_err": acc["max_err"], "eps_bound": acc["eps"],
+                          "note": "ids and score bits equal the CPU oracle by construction (canonical re-score + certificate)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, recall, bit_exact, rs = cpu_baseline(wl, va, torch, dev, n_total)
+            out["cpu_baseline"] = cb
+            out[f"recall_at_{wl['k']}"] = round(recall, 6)
+            out["recall_sample"] = rs
+            out["bit_exact_vs_oracle_on_sample"] = bit_exact
+        if world == 1 and not args.no_hbm_probe and args.workload == "cfg3":
+            # the north_star's second roofline: the memory-bound 1-query scan (configs[1])
+            ix.close()
+            w2 = WORKLOADS["cfg2"]
+            hx = va.Index(w2["dim"], w2["dtype"], w2["metric"], device=local_rank)
+            hx.add_synthetic(CORPUS_SEED, 0, w2["n"])
+            hx.set_profiling(True)
+            run_steps(hx, w2, 3, 0, 1, 0, dist, va, torch, dev)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            a2, _ = run_steps(hx, w2, 20, 3, 1, 0, dist, va, torch, dev)
+            torch.cuda.synchronize(dev)
+            e2 = time.perf_counter() - t1
+            gbps = a2["scan_bytes"] / (a2["scan_ms"] * 1e-3) / 1e9 if a2["scan_ms"] else 0.0
+            out["extra_hbm_1query"] = {
+                "workload": "cfg2: 1000000 x 768 f32 l2, batch=1, top-100", "queries_per_s": round(20 / e2, 2),
+                "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK["hbm"][0], "unit": "GB/s",
+                             "frac": round(gbps / PEAK["hbm"][0], 4), "kernel": "scan_stream_kernel",
+                             "avg_launch_ms": round(a2["scan_ms"] / max(a2["launches"], 1), 4)}}
+            hx.close()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
