@@ -90,12 +90,24 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev):
     return acc, final
 
 
+def host_cores() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(wl, va, torch, dev, n_total):
     """Oracle on this host's cores on a bounded sample; also recall@k of the HIP path on it."""
     import numpy as np
     from oracle import oracle as O
     O.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     dim, k = wl["dim"], wl["k"]
     ns = int(min(n_total, max(65536, (6 << 30) // (dim * 4))))          # <= 6 GB of fp32 rows
     ns = min(ns, 2_000_000)

@@ -1,0 +1,114 @@
+"""Host mirror of vRod's command API (vrod_amd/host, C++) through the `vrod` CLI.
+
+CPU tests: the parts the reference actually implements or shapes -- --init-database
+(src/main.rs:51-62, src/database/setup.rs:3-26), the flag set (main.rs:10-34), the
+CommandBuilder dispatch and its error (src/command/builder.rs:22-81) -- plus the loud
+failure of device commands without a GPU.  GPU test: BULKINSERT + SEARCHSIMILAR end to end
+against the oracle.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VROD = os.path.join(ROOT, "vrod_amd", "vrod")
+
+
+def run(*args, cwd=None):
+    return subprocess.run([VROD, *args], capture_output=True, text=True, cwd=cwd)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(VROD):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "vrod_amd", "host")], check=True)
+
+
+def test_no_args_prints_help():
+    r = run()
+    assert r.returncode == 2 and "--init-database" in r.stdout and "--command-arg" in r.stdout
+
+
+def test_init_database_layout_and_errors(tmp_path):
+    r = run("-i", str(tmp_path), "-n", "db1")
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(tmp_path / "db1")) == ["vr_config", "vr_wal"]
+    assert os.path.getsize(tmp_path / "db1" / "vr_wal") == 0
+    r = run("--init-database", str(tmp_path), "--init-database-name", "db1")
+    assert r.returncode == 1
+    assert f"Directory with the name 'db1' already exists in '{tmp_path}'" in r.stderr
+    r = run("-i", str(tmp_path))
+    assert r.returncode == 1
+    assert "Missing '--init_database_name' flag with argument for '--init_database' flag." in r.stderr
+
+
+def test_command_dispatch_names_and_error(tmp_path):
+    assert run("-i", str(tmp_path), "-n", "d").returncode == 0
+    db = str(tmp_path / "d")
+    r = run("-d", db, "-e", "NoSuchCommand")
+    assert r.returncode == 1 and "Unrecognized command: NoSuchCommand" in r.stderr
+    # case-insensitive names (builder.rs:29 upper-cases); the stubbed ones are accepted and do nothing
+    for name in ("truncatewal", "Update", "DELETE", "search", "ReIndex"):
+        assert run("-d", db, "-c", "x", "-e", name, "-a", "y").returncode == 0, name
+    assert run("-d", db, "-e", "create", "-a", "words metric=l2 dtype=bf16").returncode == 0
+    assert open(tmp_path / "d" / "words" / "vr_config").read().split() == ["dim=0", "metric=l2", "dtype=bf16", "count=0"]
+    r = run("-d", db, "-e", "LISTCOLLECTIONS")
+    assert r.returncode == 0 and r.stdout.split() == ["words"]
+    assert run("-d", db, "-e", "CREATE", "-a", "words").returncode == 1       # already exists
+    assert run("-d", db, "-e", "DROP", "-a", "words").returncode == 0
+    assert run("-d", db, "-e", "LISTCOLLECTIONS").stdout.strip() == ""
+    assert run("-d", db, "-c", "nope", "-e", "SEARCHSIMILAR", "-a", "1,2").returncode == 1
+    assert run("-d", str(tmp_path / "missing"), "-e", "LISTCOLLECTIONS").returncode == 1
+
+
+def test_device_commands_fail_loudly_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert run("-i", str(tmp_path), "-n", "d").returncode == 0
+    db = str(tmp_path / "d")
+    assert run("-d", db, "-e", "CREATE", "-a", "c").returncode == 0
+    r = run("-d", db, "-c", "c", "-e", "INSERT", "-a", "1,0,0;x")
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bulkinsert_and_searchsimilar_match_oracle(tmp_path, oracle):
+    n, dim, nq, k = 3000, 48, 5, 7
+    raw = oracle.synth_rows(1, 0, n, dim)
+    rq = oracle.synth_rows(2, 0, nq, dim)
+    # the reference's text format: f32::to_string values, comma-joined, ';' + word (embeddings.rs:55-61)
+    emb = tmp_path / "alice_embeddings.txt"
+    with open(emb, "w") as f:
+        for i in range(n):
+            f.write(",".join(repr(float(v)) for v in raw[i]) + f";word{i}\n")
+    assert run("-i", str(tmp_path), "-n", "d").returncode == 0
+    db = str(tmp_path / "d")
+    assert run("-d", db, "-e", "CREATE", "-a", "alice metric=cosine dtype=f32").returncode == 0
+    r = run("-d", db, "-c", "alice", "-e", "BULKINSERT", "-a", str(emb))
+    assert r.returncode == 0, r.stderr
+    assert "count=3000" in open(tmp_path / "d" / "alice" / "vr_config").read()
+    # a second process: Database::load + lazy load of the collection into HBM
+    qarg = f"k={k};" + ";".join(",".join(repr(float(v)) for v in rq[i]) for i in range(nq))
+    r = run("-d", db, "-c", "alice", "-e", "SEARCHSIMILAR", "-a", qarg)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split("\t") for l in r.stdout.strip().split("\n")]
+    assert len(rows) == nq * k
+    ids = np.array([int(x[2]) for x in rows], dtype=np.uint64).reshape(nq, k)
+    sc = np.array([float(x[3]) for x in rows], dtype=np.float32).reshape(nq, k)
+    oi, osc = oracle.search(raw, rq, k, 0, 0)
+    assert np.array_equal(ids, oi)
+    assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32))   # %.9g round-trips fp32
+    assert rows[0][4] == f"word{int(oi[0, 0])}"
+    # INSERT appends one more vector (a copy of query 0 -> it becomes query 0's best hit, id n)
+    line = ",".join(repr(float(v)) for v in rq[0]) + ";the-query"
+    assert run("-d", db, "-c", "alice", "-e", "INSERT", "-a", line).returncode == 0
+    r = run("-d", db, "-c", "alice", "-e", "SEARCHSIMILAR", "-a", "k=1;" + ",".join(repr(float(v)) for v in rq[0]))
+    assert r.returncode == 0 and r.stdout.split("\t")[2] == str(n) and r.stdout.strip().endswith("the-query")
+    # query file form
+    qf = tmp_path / "q.txt"
+    qf.write_text("\n".join(",".join(repr(float(v)) for v in rq[i]) + ";ignored" for i in range(nq)) + "\n")
+    r = run("-d", db, "-c", "alice", "-e", "SEARCHSIMILAR", "-a", f"k=3;@{qf}")
+    assert r.returncode == 0 and len(r.stdout.strip().split("\n")) == nq * 3

@@ -13,10 +13,20 @@
 // max/compare over the lane's own registers -- no cross-lane traffic in the common case.
 //
 // Staging: global -> LDS with global_load_lds_dwordx4 (LDS-DMA, 1 KB per wave instruction
-// = 8 rows x one 128-B line), two LDS stages (K-step = 128 B per row: 64 bf16 / 32 fp32).
+// = 8 rows x one 128-B line), two LDS stages (K-tile = 128 B per row: 64 bf16 / 32 fp32).
 // The LDS image is lane-linear per piece, so the bank-conflict swizzle (16-B chunk index
 // XOR row&7) is applied to the per-lane SOURCE address and again on the fragment read
 // (cdna_hip_programming.md rule 21).
+//
+// Two schedules of the same tile:
+//   scan_mfma_phased_kernel (default): 4 phases per K-tile (one 64x32 accumulator quadrant
+//     = 16 MFMAs each).  The two wave groups (rows 0-127 / 128-255; one wave of each per
+//     SIMD) run half a phase apart -- group 1 executes one extra s_barrier up front -- so
+//     on every SIMD one wave issues its LDS fragment reads and LDS-DMA staging while its
+//     partner runs MFMAs.  Raw s_barrier + counted s_waitcnt vmcnt(4): the staging of the
+//     next K-tile stays in flight across barriers and is never drained in the loop.
+//   scan_mfma_kernel: the plain double-buffered form (one __syncthreads per K-tile), kept
+//     as the A/B reference (VROD_MFMA_SIMPLE=1).
 //
 // Filter: a score that beats its query's read-only threshold is appended to an LDS log
 // (one ds_add_rtn per hit); the log is flushed to per-query lists in HBM with global
@@ -24,6 +34,9 @@
 // list_compact_kernel, so every launch of this kernel is a pure function of its inputs.
 //
 // Roofline: MFMA.  Algorithmic flops per launch = 2 * nq * rows * dim  (SURVEY.md 8d).
+#include <cstdlib>
+#include <type_traits>
+
 #include "vrod_common.h"
 #include "vrod_kernels.h"
 
@@ -38,6 +51,15 @@ constexpr int kLogCap = 2048;                     // LDS log entries (8 B each)
 constexpr int kLdsLog = 2 * kStageBytes;          // byte offset of the log
 constexpr int kLdsCtl = kLdsLog + kLogCap * 8;    // [0] log count, [1..2] flush flags
 constexpr int kLdsTotal = kLdsCtl + 64;
+
+// raw s_barrier (no vmcnt drain) fenced for the compiler only: memory operations may not be
+// moved across it, nothing is emitted for the fences
+#define VROD_BARRIER()                          \
+    do {                                        \
+        asm volatile("" ::: "memory");          \
+        __builtin_amdgcn_s_barrier();           \
+        asm volatile("" ::: "memory");          \
+    } while (0)
 
 #define VROD_GLDS16(gptr, lptr)                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),   \
@@ -73,24 +95,13 @@ __device__ __forceinline__ void global_append(const MfmaKernelArgs& a, uint32_t 
     if (pos < a.cap) a.lists[(uint64_t)gq * a.cap + pos] = make_uint2(bits, row);
 }
 
-// T = bf16_t: v_mfma_f32_16x16x32_bf16.  T = float: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).
-template <typename T, int METRIC>
-__global__ __launch_bounds__(512) void scan_mfma_kernel(const MfmaKernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint32_t* log_cnt = reinterpret_cast<uint32_t*>(lds + kLdsCtl);
-    uint32_t* flush_flag = log_cnt + 1;  // [2]
-    uint2* log = reinterpret_cast<uint2*>(lds + kLdsLog);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-
-    // ---- which (strip, query block) this work-group owns.  blockIdx % 8 labels the XCD the
-    // dispatcher tends to use, so the work-groups that share corpus tiles share an L2
-    // (speed only; nothing depends on it).
+// (strip, query block) of a work-group.  blockIdx % 8 labels the XCD the dispatcher tends to
+// use, so the work-groups that share corpus tiles share an L2 (speed only).
+__device__ __forceinline__ bool wg_assignment(const MfmaKernelArgs& a, uint32_t& strip, uint32_t& qb0,
+                                              uint32_t& qb_step) {
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    uint32_t strip, qb0, qb_step;
     if (a.nqb <= a.slots) {
-        if (slot >= a.strips_per_xcd * a.nqb) return;
+        if (slot >= a.strips_per_xcd * a.nqb) return false;
         qb0 = slot % a.nqb;
         qb_step = a.nqb;  // single pass
         strip = xcd * a.strips_per_xcd + slot / a.nqb;
@@ -99,29 +110,123 @@ __global__ __launch_bounds__(512) void scan_mfma_kernel(const MfmaKernelArgs a) 
         qb_step = a.slots;
         strip = xcd;
     }
+    return true;
+}
+
+// Drain the LDS log into the per-query lists.  Called by ALL threads at the same program
+// point with no append in flight.  Uses two block barriers.
+__device__ __forceinline__ void flush_log(const MfmaKernelArgs& a, uint2* log, uint32_t* log_cnt, uint32_t qb,
+                                          uint32_t rel_base, int tid) {
+    const uint32_t n = log_cnt[0] < (uint32_t)kLogCap ? log_cnt[0] : (uint32_t)kLogCap;
+    for (uint32_t i = tid; i < n; i += 512) {
+        const uint2 e = log[i];
+        global_append(a, qb * kBN + (e.y >> 24), e.x, rel_base + (e.y & 0xFFFFFFu));
+    }
+    __syncthreads();
+    if (tid == 0) { log_cnt[0] = 0; log_cnt[1] = 0; log_cnt[2] = 0; }
+    __syncthreads();
+}
+
+// The fused filter: the wave's 128 x 64 scores against the 4 per-lane thresholds.
+// Returns true when the LDS log passed half of its capacity (a flush is due).
+template <int METRIC>
+__device__ __forceinline__ void filter_tile(const MfmaKernelArgs& a, f32x4 (&acc)[8][4], const float (&thr)[4],
+                                            const float (&qn2)[4], uint32_t row_w, uint32_t ql0, uint32_t qb,
+                                            uint32_t rel_base, uint2* log, uint32_t* log_cnt) {
+    bool hit[4];
+    bool any = false;
+    // L2: fast distance = |q|^2 + |x|^2 - 2 q.x ; the row norms are re-read per 16-row block
+    // (L1/L2 hits) instead of held in 32 registers
+    auto xnorm_of = [&](int m) -> f32x4 {
+        if constexpr (METRIC == M_L2) return *reinterpret_cast<const f32x4*>(a.xnorm2 + row_w + m * 16);
+        else return f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto score = [&](const f32x4& xv, int m, int n, int r) -> float {
+        if constexpr (METRIC == M_COSINE) return acc[m][n][r];
+        else return __builtin_fmaf(-2.0f, acc[m][n][r], xv[r] + qn2[n]);
+    };
+    float best[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) best[n] = worst_score(METRIC);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const f32x4 xv = xnorm_of(m);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = score(xv, m, n, r);
+                best[n] = METRIC == M_COSINE ? __builtin_fmaxf(best[n], s) : __builtin_fminf(best[n], s);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        hit[n] = better<METRIC>(best[n], thr[n]);
+        any |= hit[n];
+    }
+    if (__any(any)) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 xv = xnorm_of(m);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (!__any(hit[n])) continue;
+                const uint32_t ql = ql0 + n * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = score(xv, m, n, r);
+                    const uint32_t row = row_w + m * 16 + r;
+                    if (better<METRIC>(s, thr[n]) && row >= a.row_lo && row < a.row_end) {
+                        const uint32_t pos = atomicAdd(&log_cnt[0], 1u);
+                        if (pos < (uint32_t)kLogCap) {
+                            log[pos] = make_uint2(__float_as_uint(s), (ql << 24) | (row - rel_base));
+                            if (pos >= (uint32_t)(kLogCap / 2)) log_cnt[3] = 1u;  // sticky "flush due"
+                        } else {
+                            global_append(a, qb * kBN + ql, __float_as_uint(s), row);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Schedule 1 (reference): double-buffered, one __syncthreads per K-tile.
+// T = bf16_t: v_mfma_f32_16x16x32_bf16.  T = float: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int METRIC>
+__global__ __launch_bounds__(512) void scan_mfma_kernel(const MfmaKernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint32_t* log_cnt = reinterpret_cast<uint32_t*>(lds + kLdsCtl);  // [0] count [1..2] flags [3] due
+    uint32_t* flush_flag = log_cnt + 1;
+    uint2* log = reinterpret_cast<uint2*>(lds + kLdsLog);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    uint32_t strip, qb0, qb_step;
+    if (!wg_assignment(a, strip, qb0, qb_step)) return;
     const uint32_t t0 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * strip / a.nstrips);
     const uint32_t t1 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * (strip + 1) / a.nstrips);
     if (t0 >= t1) return;
 
-    if (tid == 0) { log_cnt[0] = 0; flush_flag[0] = 0; flush_flag[1] = 0; }
+    if (tid == 0) { log_cnt[0] = 0; log_cnt[1] = 0; log_cnt[2] = 0; log_cnt[3] = 0; }
     __syncthreads();
 
-    const uint32_t KT = a.ld_bytes >> 7;  // K-steps (128 B of every row) per tile
+    const uint32_t KT = a.ld_bytes >> 7;  // K-tiles (128 B of every row) per corpus tile
     const uint32_t rel_base = a.tile_first * kBM;
-
-    // ---- per-lane staging offsets: piece = 8 rows x 128 B; lane -> (row lane>>3, chunk lane&7),
-    // the source chunk is XOR-swizzled so that the linear LDS image is conflict-free to read
     const uint32_t st_row = lane >> 3;
     const uint32_t st_lane_off = st_row * a.ld_bytes + (((lane & 7) ^ st_row) << 4);
-    // ---- per-lane fragment read offsets within a stage (A: +0, B: +32 KB)
     const uint32_t fr = lane & 15, fg = lane >> 4, r7 = fr & 7;
-    // piece of row (base + m*16 + fr) = (base>>3) + m*2 + (fr>>3); byte = piece*1024 + r7*128 + ((c ^ r7) << 4)
     const uint32_t a_frag0 = ((wr * 16 + (fr >> 3)) << 10) + (r7 << 7);
     const uint32_t b_frag0 = 32768u + ((wc * 8 + (fr >> 3)) << 10) + (r7 << 7);
     const uint32_t c_off0 = ((0 * 4 + fg) ^ r7) << 4, c_off1 = ((1 * 4 + fg) ^ r7) << 4;
 
     for (uint32_t qb = qb0; qb < a.nqb; qb += qb_step) {
-        // thresholds / norms of this lane's 4 query columns
         float thr[4], qn2[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -130,13 +235,11 @@ __global__ __launch_bounds__(512) void scan_mfma_kernel(const MfmaKernelArgs a) 
             qn2[n] = METRIC == M_L2 ? a.qnorm2[gq] : 0.0f;
         }
         const char* q_base = a.queries + (uint64_t)qb * kBN * a.ld_bytes;
-
         f32x4 acc[8][4];
 #pragma unroll
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
         const uint32_t total_it = (t1 - t0) * KT;
 
         auto stage = [&](uint32_t it, uint32_t buf) {
@@ -159,26 +262,15 @@ __global__ __launch_bounds__(512) void scan_mfma_kernel(const MfmaKernelArgs a) 
             const uint32_t buf = it & 1;
             const uint32_t kt = it % KT;
             const uint32_t tile = t0 + it / KT;
-            // ---- log flush protocol (see header): decision by thread 0 at a tile's first
-            // K-step, published by the barrier that ends that K-step, acted on here.
+            // log flush: decided by thread 0 at a tile's first K-tile, published by the barrier
+            // that ends it, acted on at the top of the next iteration (flag slot by tile parity)
             if (it > 0 && ((it - 1) % KT) == 0) {
-                const uint32_t prev_tile_parity = ((it - 1) / KT) & 1;
-                if (flush_flag[prev_tile_parity]) {
-                    const uint32_t n = log_cnt[0] < (uint32_t)kLogCap ? log_cnt[0] : (uint32_t)kLogCap;
-                    for (uint32_t i = tid; i < n; i += 512) {
-                        const uint2 e = log[i];
-                        global_append(a, qb * kBN + (e.y >> 24), e.x, rel_base + (e.y & 0xFFFFFFu));
-                    }
-                    __syncthreads();
-                    if (tid == 0) log_cnt[0] = 0;
-                    __syncthreads();
-                }
+                if (flush_flag[((it - 1) / KT) & 1]) flush_log(a, log, log_cnt, qb, rel_base, tid);
             }
             if (kt == 0 && tid == 0) flush_flag[(it / KT) & 1] = log_cnt[0] >= (uint32_t)(kLogCap / 2);
 
             if (it + 1 < total_it) stage(it + 1, buf ^ 1);
 
-            // ---- fragments + MFMA for this K-step (two 64-B halves)
             const char* l = lds + buf * kStageBytes;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -211,83 +303,225 @@ __global__ __launch_bounds__(512) void scan_mfma_kernel(const MfmaKernelArgs a) 
                                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bfr[n][i], acc[m][n], 0, 0, 0);
                 }
             }
-
-            // ---- tile finished: filter the 128 x 64 scores of this wave
-            if (kt == KT - 1) {
-                const uint32_t row_w = tile * kBM + wr * 128 + fg * 4;  // + m*16 + r
-                bool hit[4];
-                bool any = false;
-                // L2: fast distance = |q|^2 + |x|^2 - 2 q.x ; the row norms are re-read per
-                // 16-row block (L1/L2 hits) instead of held in 32 registers
-                auto xnorm_of = [&](int m) -> f32x4 {
-                    if constexpr (METRIC == M_L2) return *reinterpret_cast<const f32x4*>(a.xnorm2 + row_w + m * 16);
-                    else return f32x4{0.f, 0.f, 0.f, 0.f};
-                };
-                auto score = [&](const f32x4& xv, int m, int n, int r) -> float {
-                    if constexpr (METRIC == M_COSINE) return acc[m][n][r];
-                    else return __builtin_fmaf(-2.0f, acc[m][n][r], xv[r] + qn2[n]);
-                };
-                float best[4];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) best[n] = worst_score(METRIC);
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const f32x4 xv = xnorm_of(m);
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float s = score(xv, m, n, r);
-                            best[n] = METRIC == M_COSINE ? __builtin_fmaxf(best[n], s) : __builtin_fminf(best[n], s);
-                        }
-                }
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    hit[n] = better<METRIC>(best[n], thr[n]);
-                    any |= hit[n];
-                }
-                if (__any(any)) {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        const f32x4 xv = xnorm_of(m);
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            if (!__any(hit[n])) continue;
-                            const uint32_t ql = wc * 64 + n * 16 + fr;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float s = score(xv, m, n, r);
-                                const uint32_t row = row_w + m * 16 + r;
-                                if (better<METRIC>(s, thr[n]) && row >= a.row_lo && row < a.row_end) {
-                                    const uint32_t pos = atomicAdd(&log_cnt[0], 1u);
-                                    if (pos < (uint32_t)kLogCap)
-                                        log[pos] = make_uint2(__float_as_uint(s), (ql << 24) | (row - rel_base));
-                                    else
-                                        global_append(a, qb * kBN + ql, __float_as_uint(s), row);
-                                }
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            if (kt == KT - 1)
+                filter_tile<METRIC>(a, acc, thr, qn2, tile * kBM + wr * 128 + fg * 4, wc * 64 + fr, qb, rel_base, log, log_cnt);
             __syncthreads();  // stage it+1 landed (vmcnt(0) + barrier); buf may be restaged
         }
+        flush_log(a, log, log_cnt, qb, rel_base, tid);
+    }
+}
 
-        // ---- end of this query block: flush what is left in the log
-        {
-            const uint32_t n = log_cnt[0] < (uint32_t)kLogCap ? log_cnt[0] : (uint32_t)kLogCap;
-            for (uint32_t i = tid; i < n; i += 512) {
-                const uint2 e = log[i];
-                global_append(a, qb * kBN + (e.y >> 24), e.x, rel_base + (e.y & 0xFFFFFFu));
-            }
-            __syncthreads();
-            if (tid == 0) { log_cnt[0] = 0; flush_flag[0] = 0; flush_flag[1] = 0; }
-            __syncthreads();
+// ---------------------------------------------------------------------------------------------
+// Schedule 2 (default): staggered wave groups, 4 phases per K-tile, counted vmcnt.
+//
+// Phase p of a K-tile works on accumulator quadrant (mh, nh) = (0,0) (0,1) (1,1) (1,0):
+//   LOAD    : ds_read the fragments the quadrant needs that are not in registers yet
+//             (p0: A rows mh=0 + B cols nh=0, p1: B nh=1, p2: A mh=1, p3: B nh=0), and issue
+//             2 LDS-DMA pieces of one staging unit of the NEXT K-tile
+//             (p0: A_m0, p1: B_n0, p2: B_n1, p3: A_m1 -- the order of first use);
+//             s_waitcnt vmcnt(4): all but the 2 youngest units this wave issued have landed
+//   s_barrier
+//   COMPUTE : 16 MFMAs (4 x 2 tiles x 2 k-halves), s_setprio 1 around them
+//   s_barrier
+// Group 1 (waves 4-7) runs one barrier behind group 0, so LOAD of one group overlaps COMPUTE
+// of the other on every SIMD.  Hazards (cdna_hip_programming.md "Read a staged buffer one
+// phase AFTER the wait that retires it"): a unit is read >= 1 phase after every wave's
+// vmcnt wait for it plus a barrier, and restaged >= 2 phases after its last read.
+// ---------------------------------------------------------------------------------------------
+// GP = how many of a phase's 2 LDS-DMA pieces are issued inside the MFMA cluster instead of next
+// to the ds_reads (an LDS-DMA issue is ~2-3x cheaper among MFMAs than beside LDS reads, and
+// the load segment is the one that must not outlast the partner's 256-cycle MFMA segment).
+// The unit issue order per wave is unchanged, so the counted wait is vmcnt(4 - GP).
+template <typename T, int METRIC, int GP>
+__global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint32_t* log_cnt = reinterpret_cast<uint32_t*>(lds + kLdsCtl);  // [0] count [3] flush due
+    uint2* log = reinterpret_cast<uint2*>(lds + kLdsLog);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    uint32_t strip, qb0, qb_step;
+    if (!wg_assignment(a, strip, qb0, qb_step)) return;
+    const uint32_t t0 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * strip / a.nstrips);
+    const uint32_t t1 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * (strip + 1) / a.nstrips);
+    if (t0 >= t1) return;
+
+    if (tid == 0) { log_cnt[0] = 0; log_cnt[1] = 0; log_cnt[2] = 0; log_cnt[3] = 0; }
+    __syncthreads();
+
+    const uint32_t KT = a.ld_bytes >> 7;
+    const uint32_t rel_base = a.tile_first * kBM;
+    const uint32_t st_row = lane >> 3;
+    const uint32_t st_lane_off = st_row * a.ld_bytes + (((lane & 7) ^ st_row) << 4);
+    const uint32_t fr = lane & 15, fg = lane >> 4, r7 = fr & 7;
+    const uint32_t a_frag0 = ((wr * 16 + (fr >> 3)) << 10) + (r7 << 7);
+    const uint32_t b_frag0 = 32768u + ((wc * 8 + (fr >> 3)) << 10) + (r7 << 7);
+    const uint32_t c_off0 = ((0 * 4 + fg) ^ r7) << 4, c_off1 = ((1 * 4 + fg) ^ r7) << 4;
+
+    // staging pieces of this wave inside each unit (16 pieces per unit, 2 per wave):
+    //   A_m0 = pieces {0-7,16-23}, A_m1 = +8;  B_n0 = pieces {0-3,8-11,16-19,24-27}, B_n1 = +4
+    uint32_t pa[2], pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t idx = wave * 2 + i;
+        pa[i] = (idx & 7) + (idx >> 3) * 16;
+        pb[i] = (idx & 3) + (idx >> 2) * 8;
+    }
+
+    for (uint32_t qb = qb0; qb < a.nqb; qb += qb_step) {
+        float thr[4], qn2[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const uint32_t gq = qb * kBN + wc * 64 + n * 16 + fr;
+            thr[n] = a.thr[gq];
+            qn2[n] = METRIC == M_L2 ? a.qnorm2[gq] : 0.0f;
         }
+        const char* q_base = a.queries + (uint64_t)qb * kBN * a.ld_bytes + st_lane_off;
+        const char* c_base = a.corpus + st_lane_off;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint32_t total_it = (t1 - t0) * KT;
+
+        // ---- prologue: the whole K-tile 0 into buffer 0, fully landed, groups not yet staggered
+        {
+            const char* a_src = c_base + (uint64_t)t0 * kBM * a.ld_bytes;
+            const char* b_src = q_base;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                VROD_GLDS16(a_src + (uint64_t)pa[i] * 8 * a.ld_bytes, lds + pa[i] * 1024);
+                VROD_GLDS16(a_src + (uint64_t)(pa[i] + 8) * 8 * a.ld_bytes, lds + (pa[i] + 8) * 1024);
+                VROD_GLDS16(b_src + (uint64_t)pb[i] * 8 * a.ld_bytes, lds + 32768 + pb[i] * 1024);
+                VROD_GLDS16(b_src + (uint64_t)(pb[i] + 4) * 8 * a.ld_bytes, lds + 32768 + (pb[i] + 4) * 1024);
+            }
+        }
+        __syncthreads();                       // vmcnt(0) + barrier
+        if (wr == 1) VROD_BARRIER();   // group 1 now runs one barrier behind
+
+        // fragment registers: A half (4 m-tiles x 2 k-halves), B half (2 n-tiles x 2 k-halves)
+        typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type frag_t;
+        frag_t af[4][2], bf[2][2];
+
+        for (uint32_t it = 0; it < total_it; ++it) {
+            const uint32_t buf = it & 1;
+            const char* l = lds + buf * kStageBytes;
+            char* lnext = lds + (buf ^ 1) * kStageBytes;
+            // source of the NEXT K-tile (clamped at the end: the redundant loads keep the
+            // vmcnt bookkeeping uniform and are never read)
+            const uint32_t nx = it + 1 < total_it ? it + 1 : it;
+            const uint32_t ntile = t0 + nx / KT, nkt = nx % KT;
+            const char* a_src = c_base + (uint64_t)ntile * kBM * a.ld_bytes + (uint64_t)nkt * 128;
+            const char* b_src = q_base + (uint64_t)nkt * 128;
+            const uint32_t kt = it % KT;
+
+            // the log is flushed with both groups re-aligned, one phase after a tile's first
+            // (see below); `due` is read where no append can be in flight in either group
+            bool flush_now = false;
+
+#define VROD_LOAD_A(MH)                                                                                   \
+    _Pragma("unroll") for (int mm = 0; mm < 4; ++mm) {                                                   \
+        af[mm][0] = *reinterpret_cast<const frag_t*>(l + a_frag0 + ((MH) * 4 + mm) * 2048 + c_off0);    \
+        af[mm][1] = *reinterpret_cast<const frag_t*>(l + a_frag0 + ((MH) * 4 + mm) * 2048 + c_off1);    \
+    }
+#define VROD_LOAD_B(NH)                                                                                   \
+    _Pragma("unroll") for (int nn = 0; nn < 2; ++nn) {                                                   \
+        bf[nn][0] = *reinterpret_cast<const frag_t*>(l + b_frag0 + ((NH) * 2 + nn) * 2048 + c_off0);    \
+        bf[nn][1] = *reinterpret_cast<const frag_t*>(l + b_frag0 + ((NH) * 2 + nn) * 2048 + c_off1);    \
+    }
+#define VROD_STAGE_A1(OFF, I)                                                                             \
+    VROD_GLDS16(a_src + (uint64_t)(pa[I] + (OFF)) * 8 * a.ld_bytes, lnext + (pa[I] + (OFF)) * 1024);
+#define VROD_STAGE_B1(OFF, I)                                                                             \
+    VROD_GLDS16(b_src + (uint64_t)(pb[I] + (OFF)) * 8 * a.ld_bytes, lnext + 32768 + (pb[I] + (OFF)) * 1024);
+// pieces issued in the load segment / inside the MFMA cluster
+#define VROD_STAGE_L(KIND, OFF)                                                                           \
+    if constexpr (GP <= 1) { VROD_STAGE_##KIND##1(OFF, 0) }                                               \
+    if constexpr (GP == 0) { VROD_STAGE_##KIND##1(OFF, 1) }
+#define VROD_MFMA_ONE(MH, NH, KK, MM, NN)                                                                 \
+    if constexpr (sizeof(T) == 2) {                                                                       \
+        acc[(MH) * 4 + MM][(NH) * 2 + NN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+            af[MM][KK], bf[NN][KK], acc[(MH) * 4 + MM][(NH) * 2 + NN], 0, 0, 0);                          \
+    } else {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+            acc[(MH) * 4 + MM][(NH) * 2 + NN] = __builtin_amdgcn_mfma_f32_16x16x4f32(                     \
+                af[MM][KK][i], bf[NN][KK][i], acc[(MH) * 4 + MM][(NH) * 2 + NN], 0, 0, 0);                \
+    }
+#define VROD_MFMA_ROW(MH, NH, KK, MM) VROD_MFMA_ONE(MH, NH, KK, MM, 0) VROD_MFMA_ONE(MH, NH, KK, MM, 1)
+// 16 MFMAs; DMA pieces dropped in after the 4th and the 10th when GP says so
+#define VROD_COMPUTE(MH, NH, KIND, OFF)                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    VROD_MFMA_ROW(MH, NH, 0, 0) VROD_MFMA_ROW(MH, NH, 0, 1)                                               \
+    if constexpr (GP == 2) { VROD_STAGE_##KIND##1(OFF, 0) }                                               \
+    VROD_MFMA_ROW(MH, NH, 0, 2) VROD_MFMA_ROW(MH, NH, 0, 3) VROD_MFMA_ROW(MH, NH, 1, 0)                   \
+    if constexpr (GP >= 1) { VROD_STAGE_##KIND##1(OFF, 1) }                                               \
+    VROD_MFMA_ROW(MH, NH, 1, 1) VROD_MFMA_ROW(MH, NH, 1, 2) VROD_MFMA_ROW(MH, NH, 1, 3)                   \
+    __builtin_amdgcn_s_setprio(0);
+#define VROD_PHASE_SYNC()                                                                                 \
+    if constexpr (GP == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                               \
+    else if constexpr (GP == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                          \
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                 \
+    VROD_BARRIER();
+
+            // ---------------- phase 0: quadrant (0,0), stages A_m0 of the next K-tile
+            VROD_LOAD_A(0)
+            VROD_LOAD_B(0)
+            VROD_STAGE_L(A, 0)
+            VROD_PHASE_SYNC()
+            VROD_COMPUTE(0, 0, A, 0)
+            VROD_BARRIER();
+
+            // ---------------- phase 1: quadrant (0,1), stages B_n0
+            if (kt == 0 && it > 0) flush_now = log_cnt[3] != 0u;  // previous tile's appends are all done
+            VROD_LOAD_B(1)
+            VROD_STAGE_L(B, 0)
+            VROD_PHASE_SYNC()
+            VROD_COMPUTE(0, 1, B, 0)
+            VROD_BARRIER();
+
+            // ---------------- phase 2: quadrant (1,1), stages B_n1
+            VROD_LOAD_A(1)
+            VROD_STAGE_L(B, 4)
+            VROD_PHASE_SYNC()
+            VROD_COMPUTE(1, 1, B, 4)
+            VROD_BARRIER();
+
+            // ---------------- phase 3: quadrant (1,0), stages A_m1
+            VROD_LOAD_B(0)
+            VROD_STAGE_L(A, 8)
+            VROD_PHASE_SYNC()
+            VROD_COMPUTE(1, 0, A, 8)
+            if (kt == KT - 1) {
+                const uint32_t tile = t0 + it / KT;
+                filter_tile<METRIC>(a, acc, thr, qn2, tile * kBM + wr * 128 + fg * 4, wc * 64 + fr, qb, rel_base, log, log_cnt);
+            }
+            VROD_BARRIER();
+
+            if (flush_now) {
+                // re-align the groups (group 0 waits one barrier), flush, stagger again
+                if (wr == 0) VROD_BARRIER();
+                flush_log(a, log, log_cnt, qb, rel_base, tid);
+                if (tid == 0) log_cnt[3] = 0u;
+                __syncthreads();
+                if (wr == 1) VROD_BARRIER();
+            }
+        }
+#undef VROD_LOAD_A
+#undef VROD_LOAD_B
+#undef VROD_STAGE_A1
+#undef VROD_STAGE_B1
+#undef VROD_STAGE_L
+#undef VROD_MFMA_ONE
+#undef VROD_MFMA_ROW
+#undef VROD_COMPUTE
+#undef VROD_PHASE_SYNC
+        if (wr == 0) VROD_BARRIER();   // group 0 waits for group 1's last phase
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        flush_log(a, log, log_cnt, qb, rel_base, tid);
+        if (tid == 0) log_cnt[3] = 0u;
+        __syncthreads();
     }
 }
 
@@ -313,19 +547,39 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     a.slots = grid / 8;
     a.strips_per_xcd = a.nqb <= a.slots ? a.slots / a.nqb : 1;
     a.nstrips = 8 * a.strips_per_xcd;
-    // fewer tiles than strips: shrink the strip count so no strip is empty more than needed
-#define VROD_MFMA(TT, MM)                                                                                   \
+    static const bool simple = [] { const char* e = getenv("VROD_MFMA_SIMPLE"); return e && e[0] == '1'; }();
+#define VROD_MFMA(KERNEL, TT, MM)                                                                           \
     do {                                                                                                    \
         static bool attr_set = false;                                                                       \
         if (!attr_set) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)scan_mfma_kernel<TT, MM>,                                \
+            (void)hipFuncSetAttribute((const void*)KERNEL<TT, MM>,                                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);               \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        scan_mfma_kernel<TT, MM><<<grid, 512, kLdsTotal, s>>>(a);                                           \
+        KERNEL<TT, MM><<<grid, 512, kLdsTotal, s>>>(a);                                                     \
     } while (0)
-    if (dtype == DT_BF16) { if (h.metric == M_COSINE) VROD_MFMA(bf16_t, M_COSINE); else VROD_MFMA(bf16_t, M_L2); }
-    else { if (h.metric == M_COSINE) VROD_MFMA(float, M_COSINE); else VROD_MFMA(float, M_L2); }
+    static const int gp = [] { const char* e = getenv("VROD_MFMA_GP"); return e ? atoi(e) : 0; }();
+#define VROD_MFMA_P(TT, MM, GPV)                                                                            \
+    do {                                                                                                    \
+        static bool attr_set = false;                                                                       \
+        if (!attr_set) {                                                                                    \
+            (void)hipFuncSetAttribute((const void*)scan_mfma_phased_kernel<TT, MM, GPV>,                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);               \
+            attr_set = true;                                                                                \
+        }                                                                                                   \
+        scan_mfma_phased_kernel<TT, MM, GPV><<<grid, 512, kLdsTotal, s>>>(a);                               \
+    } while (0)
+#define VROD_MFMA_BOTH(TT, MM)                                                                              \
+    do {                                                                                                    \
+        if (simple) VROD_MFMA(scan_mfma_kernel, TT, MM);                                                    \
+        else if (gp == 1) VROD_MFMA_P(TT, MM, 1);                                                           \
+        else if (gp == 2) VROD_MFMA_P(TT, MM, 2);                                                           \
+        else VROD_MFMA_P(TT, MM, 0);                                                                        \
+    } while (0)
+    if (dtype == DT_BF16) { if (h.metric == M_COSINE) VROD_MFMA_BOTH(bf16_t, M_COSINE); else VROD_MFMA_BOTH(bf16_t, M_L2); }
+    else { if (h.metric == M_COSINE) VROD_MFMA_BOTH(float, M_COSINE); else VROD_MFMA_BOTH(float, M_L2); }
+#undef VROD_MFMA_BOTH
+#undef VROD_MFMA_P
 #undef VROD_MFMA
 }
 

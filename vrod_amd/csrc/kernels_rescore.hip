@@ -12,7 +12,7 @@
 //
 // Layout: one lane owns one (query, candidate row) chain.  A wave stages 64 candidate
 // rows x 64 elements through an LDS tile (coalesced 256-B / 128-B row segments in,
-// conflict-free column walk out: row stride 65 dwords).
+// 16-B column walk out: row stride 68 dwords).
 #include "vrod_common.h"
 #include "vrod_kernels.h"
 
@@ -34,27 +34,37 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
     return r;
 }
 
-constexpr int kTileStride = 65;
+constexpr int kTileStride = 68;  // dwords: 16-B aligned rows, conflict-free b128 column walk
 
-// ALL == false: candidates d_cand_rows[q][kp] (~0u = empty).  grid = (ceil(kp/256), nq).
-// ALL == true : rows blockIdx.x*256 + ... of the shard for the single query d_q. grid = (ceil(n/256), 1).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// One wave per block.  ALL == false: the block owns candidate slots [64*blockIdx.x, +64) of
+// query blockIdx.y (rows from d_cand_rows, ~0u = empty; empties sit at the end of a list).
+// ALL == true: rows [64*blockIdx.x, +64) of the shard for the single query d_q.
+// Each 64-element chunk of the 64 rows is fetched with 16-B loads, all issued before the
+// first LDS write (the chain itself is sequential, the loads must not be), and then every
+// lane walks its own row of the tile in order.
 template <typename T, int METRIC, bool ALL>
-__global__ __launch_bounds__(256) void rescore_kernel(const T* __restrict__ corpus, uint32_t dim,
-                                                      uint32_t ld, const float* __restrict__ q,
-                                                      const uint32_t* __restrict__ cand_rows,
-                                                      uint32_t kp, uint64_t nrows,
-                                                      float* __restrict__ out) {
+__global__ __launch_bounds__(64) void rescore_kernel(const T* __restrict__ corpus, uint32_t dim,
+                                                     uint32_t ld, const float* __restrict__ q,
+                                                     const uint32_t* __restrict__ cand_rows,
+                                                     uint32_t kp, uint64_t nrows,
+                                                     float* __restrict__ out) {
+    constexpr int EPU = 16 / (int)sizeof(T);   // elements per 16-B load: 4 fp32 / 8 bf16
+    constexpr int LPC = 64 / EPU;              // lanes covering one row's 64-element chunk
+    constexpr int RPI = 64 / LPC;              // rows per load instruction
+    constexpr int NI = 64 / RPI;               // load instructions per chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* q_lds = smem;                                   // [ld]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* tile = smem + ld + wave * (64 * kTileStride);   // [64][65]
+    float* q_lds = smem;                       // [ld]
+    float* tile = smem + ld;                   // [64][68]
+    const int lane = threadIdx.x;
 
     const uint32_t qi = ALL ? 0u : blockIdx.y;
     const float* qrow = q + (uint64_t)qi * ld;
-    for (uint32_t i = threadIdx.x; i < ld; i += blockDim.x) q_lds[i] = qrow[i];
-    __syncthreads();
+    for (uint32_t i = lane; i < ld; i += 64) q_lds[i] = qrow[i];
 
-    const uint64_t slot = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // candidate slot / row
+    const uint64_t slot = (uint64_t)blockIdx.x * 64 + lane;
     uint32_t my_row;
     bool valid;
     if constexpr (ALL) {
@@ -65,43 +75,62 @@ __global__ __launch_bounds__(256) void rescore_kernel(const T* __restrict__ corp
         valid = my_row != 0xFFFFFFFFu;
         if (!valid) my_row = 0u;
     }
-    // whole wave idle? (uniform) -- still must not skip the barrier above, which is done
-    if (__ballot(valid) != 0ull) {
-        float acc = 0.0f;
-        for (uint32_t j0 = 0; j0 < dim; j0 += 64) {
-            const uint32_t j = j0 + lane;
-#pragma unroll 8
-            for (int c = 0; c < 64; ++c) {
-                const uint32_t row_c = __shfl(my_row, c);
-                float v = 0.0f;
-                if (j < dim) {
-                    if constexpr (sizeof(T) == 2) v = bf16_to_f32(corpus[(uint64_t)row_c * ld + j]);
-                    else v = corpus[(uint64_t)row_c * ld + j];
-                }
-                tile[c * kTileStride + lane] = v;
+    const unsigned long long vmask = __ballot(valid);
+    if (vmask == 0ull) return;  // whole wave idle (single-wave block: no barrier is skipped)
+    // valid slots are a prefix of the wave; rows beyond it are not fetched
+    const int nvalid = 64 - __builtin_clzll(vmask);
+    const int ni_used = (nvalid + RPI - 1) / RPI;
+    const int sub = lane / LPC, part = lane % LPC;
+
+    float acc = 0.0f;
+    for (uint32_t j0 = 0; j0 < dim; j0 += 64) {
+        u32x4 v[NI];
+        const uint32_t e0 = j0 + part * EPU;  // first element this lane fetches
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            v[it] = u32x4{0u, 0u, 0u, 0u};
+            if (it < ni_used) {
+                const uint32_t row = __shfl(my_row, it * RPI + sub);
+                if (e0 < ld) v[it] = *reinterpret_cast<const u32x4*>(corpus + (uint64_t)row * ld + e0);
             }
-            // tile is private to the wave: wave-level ordering of LDS ops suffices
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t jn = dim - j0 < 64 ? dim - j0 : 64;
-            for (uint32_t l = 0; l < jn; ++l) {
-                const float x = tile[lane * kTileStride + l];
-                const float qq = q_lds[j0 + l];
-                if constexpr (METRIC == M_COSINE) {
-                    acc = add_rn(acc, mul_rn(qq, x));
-                } else {
-                    const float d = sub_rn(qq, x);
-                    acc = add_rn(acc, mul_rn(d, d));
+        }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            float* t = tile + (it * RPI + sub) * kTileStride + part * EPU;
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<u32x4*>(t) = v[it];
+            } else {
+                *reinterpret_cast<u32x4*>(t) = u32x4{v[it].x << 16, v[it].x & 0xFFFF0000u, v[it].y << 16, v[it].y & 0xFFFF0000u};
+                *reinterpret_cast<u32x4*>(t + 4) = u32x4{v[it].z << 16, v[it].z & 0xFFFF0000u, v[it].w << 16, v[it].w & 0xFFFF0000u};
+            }
+        }
+        // the tile (and q_lds on the first pass) is wave-private: in-order LDS + a compiler fence
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t jn = dim - j0 < 64 ? dim - j0 : 64;
+        const float* trow = tile + lane * kTileStride;
+        for (uint32_t l = 0; l < jn; l += 4) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(trow + l);
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(q_lds + j0 + l);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (l + e < jn) {
+                    if constexpr (METRIC == M_COSINE) {
+                        acc = add_rn(acc, mul_rn(qq[e], x[e]));
+                    } else {
+                        const float d = sub_rn(qq[e], x[e]);
+                        acc = add_rn(acc, mul_rn(d, d));
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (ALL) {
-            if (valid) out[slot] = acc;
-        } else {
-            if (slot < kp) out[(uint64_t)qi * kp + slot] = valid ? acc : __uint_as_float(kScoreNoneBits);
-        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (ALL) {
+        if (valid) out[slot] = acc;
+    } else {
+        if (slot < kp) out[(uint64_t)qi * kp + slot] = valid ? acc : __uint_as_float(kScoreNoneBits);
     }
 }
 
@@ -109,9 +138,9 @@ template <bool ALL>
 static void launch_rescore(const void* d_corpus, int dtype, int metric, uint32_t dim, uint32_t ld,
                            const float* d_q, int nq, const uint32_t* d_cand_rows, uint32_t kp,
                            uint64_t nrows, float* d_out, hipStream_t s) {
-    const size_t lds = ((size_t)ld + 4 * 64 * kTileStride) * sizeof(float);
-    dim3 grid(ALL ? (unsigned)((nrows + 255) / 256) : (kp + 255) / 256, ALL ? 1 : nq);
-#define VROD_RS(TT, MM) rescore_kernel<TT, MM, ALL><<<grid, 256, lds, s>>>((const TT*)d_corpus, dim, ld, d_q, d_cand_rows, kp, nrows, d_out)
+    const size_t lds = ((size_t)ld + 64 * kTileStride) * sizeof(float);
+    dim3 grid(ALL ? (unsigned)((nrows + 63) / 64) : (kp + 63) / 64, ALL ? 1 : nq);
+#define VROD_RS(TT, MM) rescore_kernel<TT, MM, ALL><<<grid, 64, lds, s>>>((const TT*)d_corpus, dim, ld, d_q, d_cand_rows, kp, nrows, d_out)
     if (dtype == DT_BF16) { if (metric == M_COSINE) VROD_RS(bf16_t, M_COSINE); else VROD_RS(bf16_t, M_L2); }
     else { if (metric == M_COSINE) VROD_RS(float, M_COSINE); else VROD_RS(float, M_L2); }
 #undef VROD_RS

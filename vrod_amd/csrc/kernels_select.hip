@@ -18,21 +18,68 @@ namespace vrod {
 constexpr int kSortThreads = 1024;
 
 // ------------------------------------------------------------------ block bitonic sort (descending)
-// n is a power of two, n <= kSelectChunk.  All kSortThreads threads call this.
+// n is a power of two, 2 <= n <= kSelectChunk.  All kSortThreads threads call this.
+// Each of the W active waves owns a contiguous segment of S = n/W >= 128 keys.  A stage whose
+// stride j is < S only pairs keys inside one segment, so it needs no block barrier: LDS
+// operations of one wave execute in order, a compiler fence is enough.  Only the log2(W)
+// largest strides of each merge step are block-wide (10 of 91 stages at n = 8192).
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* __restrict__ a, uint32_t n) {
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr uint32_t kWaves = kSortThreads / 64;
+    const uint32_t W = n / 128 < kWaves ? (n / 128 ? n / 128 : 1) : kWaves;  // active waves
+    const uint32_t S = n / W;                                                 // keys per segment
+    const bool active = wave < W;
+    bool dirty_local = false;  // local stages ran since the last block barrier
     for (uint32_t k = 2; k <= n; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (n >> 1); t += kSortThreads) {
-                const uint32_t i = 2 * t - (t & (j - 1));
-                const uint32_t l = i + j;
-                const bool up = (i & k) == 0;
-                const uint64_t x = a[i], y = a[l];
-                if ((x < y) == up) { a[i] = y; a[l] = x; }
+            if (j >= S) {
+                // block-wide stage
+                if (dirty_local) { __syncthreads(); dirty_local = false; }
+                for (uint32_t t = tid; t < (n >> 1); t += kSortThreads) {
+                    const uint32_t i = 2 * t - (t & (j - 1));
+                    const uint32_t l = i + j;
+                    const bool up = (i & k) == 0;
+                    const uint64_t x = a[i], y = a[l];
+                    if ((x < y) == up) { a[i] = y; a[l] = x; }
+                }
+                __syncthreads();
+            } else {
+                // segment-local stage: wave `wave` handles compare-exchanges of its own segment
+                if (active) {
+                    const uint32_t base = wave * S;
+                    for (uint32_t t = lane; t < (S >> 1); t += 64) {
+                        const uint32_t i = base + 2 * t - (t & (j - 1));
+                        const uint32_t l = i + j;
+                        const bool up = (i & k) == 0;
+                        const uint64_t x = a[i], y = a[l];
+                        if ((x < y) == up) { a[i] = y; a[l] = x; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                dirty_local = true;
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ small sets: rank sort
+// Keys are unique (they embed the row), so an element's position in descending order is the
+// number of keys larger than it.  Every lane reads the same LDS word per step (broadcast,
+// conflict-free) -- no barriers, n^2/threads compares: the cheaper sort below ~2K keys.
+// a[0..n) unsorted in LDS, tmp[0..n) receives the sorted keys.  Ends with a barrier.
+constexpr uint32_t kRankSortMax = 128;
+__device__ __forceinline__ void rank_sort_desc(const uint64_t* __restrict__ a, uint64_t* __restrict__ tmp, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t mine = a[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += a[j] > mine;
+        // duplicates can only be padding zeros: give them distinct slots at the end
+        if (mine == 0ull) { for (uint32_t j = 0; j < i; ++j) rank += a[j] == 0ull; }
+        tmp[rank] = mine;
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ uint32_t pow2_ceil(uint32_t n) {
@@ -99,33 +146,107 @@ uint64_t launch_select_from_keys(const uint64_t* d_in, uint64_t in_ld, uint64_t 
 }
 
 // ------------------------------------------------------------------ keys -> candidates
-// One block per query, n <= kSelectChunk keys.  Sort, emit kp rows + fast scores + T.
+// One block per query, n <= kSelectChunk keys (n = min(cnt[q], n_max) when cnt is given).
+// Sort, emit kp rows + fast scores + T.
 __global__ __launch_bounds__(kSortThreads) void keys_to_candidates_kernel(
-    const uint64_t* __restrict__ keys, uint64_t key_ld, uint32_t n, int metric, uint32_t kp,
-    uint32_t* __restrict__ cand_rows, float* __restrict__ cand_fast, float* __restrict__ T) {
+    const uint64_t* __restrict__ keys, uint64_t key_ld, uint32_t n_max, const uint32_t* __restrict__ cnt,
+    int metric, uint32_t kp, uint32_t* __restrict__ cand_rows, float* __restrict__ cand_fast,
+    float* __restrict__ T) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
     const uint32_t q = blockIdx.x;
-    const uint32_t np2 = pow2_ceil(n < 2 ? 2 : n);
-    for (uint32_t i = threadIdx.x; i < np2; i += kSortThreads)
-        skeys[i] = i < n ? keys[(uint64_t)q * key_ld + i] : 0ull;
-    __syncthreads();
-    bitonic_sort_desc(skeys, np2);
+    uint32_t n = n_max;
+    if (cnt) n = cnt[q] < n_max ? cnt[q] : n_max;
+    const uint64_t* sorted;
+    uint32_t nsorted;
+    if (n <= kRankSortMax) {
+        for (uint32_t i = threadIdx.x; i < n; i += kSortThreads) skeys[i] = keys[(uint64_t)q * key_ld + i];
+        __syncthreads();
+        rank_sort_desc(skeys, skeys + kRankSortMax, n);
+        sorted = skeys + kRankSortMax;
+        nsorted = n;
+    } else {
+        const uint32_t np2 = pow2_ceil(n);
+        for (uint32_t i = threadIdx.x; i < np2; i += kSortThreads)
+            skeys[i] = i < n ? keys[(uint64_t)q * key_ld + i] : 0ull;
+        __syncthreads();
+        bitonic_sort_desc(skeys, np2);
+        sorted = skeys;
+        nsorted = np2;
+    }
     for (uint32_t i = threadIdx.x; i < kp; i += kSortThreads) {
-        const uint64_t key = i < np2 ? skeys[i] : 0ull;
+        const uint64_t key = i < nsorted ? sorted[i] : 0ull;
         cand_rows[(uint64_t)q * kp + i] = key ? key_row(key) : 0xFFFFFFFFu;
         cand_fast[(uint64_t)q * kp + i] = key ? key_to_score_rt(key_skey(key), metric) : __uint_as_float(kScoreNoneBits);
     }
     if (threadIdx.x == 0) {
         // kp-th candidate present -> rows left out all have a fast score no better than it
-        const uint64_t last = kp <= np2 ? skeys[kp - 1] : 0ull;
+        const uint64_t last = kp <= nsorted ? sorted[kp - 1] : 0ull;
         T[q] = last ? key_to_score_rt(key_skey(last), metric) : worst_score(metric);
     }
 }
 
 void launch_keys_to_candidates(const uint64_t* d_keys, uint64_t key_ld, uint64_t n, int nq,
                                int metric, uint32_t kp, uint32_t* d_cand_rows, float* d_cand_fast,
-                               float* d_T, hipStream_t s) {
-    keys_to_candidates_kernel<<<nq, kSortThreads, sort_lds_bytes(n), s>>>(d_keys, key_ld, (uint32_t)n, metric, kp, d_cand_rows, d_cand_fast, d_T);
+                               float* d_T, const uint32_t* d_cnt, hipStream_t s) {
+    // LDS: bitonic needs pow2(n) keys; the rank sort needs 2 * kRankSortMax
+    size_t lds = sort_lds_bytes(n);
+    if (lds < 2 * kRankSortMax * sizeof(uint64_t)) lds = 2 * kRankSortMax * sizeof(uint64_t);
+    keys_to_candidates_kernel<<<nq, kSortThreads, lds, s>>>(d_keys, key_ld, (uint32_t)n, d_cnt, metric, kp, d_cand_rows, d_cand_fast, d_T);
+}
+
+// ------------------------------------------------------------------ radix-select step 2 (stream path)
+// grid = (blocks over the score array, nq).  Every block re-derives the cut bin from the
+// global histogram (a few KB, L2-resident) -- cheaper than one more launch -- and then
+// compacts its slice: rows whose key is in the cut bin or a better one.
+constexpr uint32_t kCompactSlice = 8192;
+template <int METRIC>
+__global__ __launch_bounds__(256) void hist_compact_kernel(const float* __restrict__ scores, uint64_t score_ld,
+                                                           uint64_t n, const uint32_t* __restrict__ ghist,
+                                                           int hist_bits, uint32_t kp, uint64_t* __restrict__ keys,
+                                                           uint32_t cap, uint32_t* __restrict__ cnt,
+                                                           uint32_t* __restrict__ status) {
+    __shared__ uint32_t ctl[8];
+    const uint32_t q = blockIdx.y;
+    const int nbins = 1 << hist_bits;
+    block_find_cut_bin(ghist + (size_t)q * nbins, nbins, kp, ctl);
+    const uint32_t cut = ctl[4], n_ge = ctl[5];
+    if (n_ge > cap) {  // too many rows share the cut bin (heavy ties): the exact path takes over
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[q], 2u);
+        return;
+    }
+    const uint32_t thr_key = cut << (32 - hist_bits);
+    const uint64_t i0 = (uint64_t)blockIdx.x * kCompactSlice;
+    const float* sc = scores + (uint64_t)q * score_ld;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t off = threadIdx.x; off < kCompactSlice; off += 256) {
+        const uint64_t i = i0 + off;
+        uint32_t skey = 0;
+        bool take = false;
+        if (i < n) {
+            skey = score_key<METRIC>(sc[i]);
+            take = skey >= thr_key;
+        }
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&cnt[q], (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (take) {
+                const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < cap) keys[(uint64_t)q * cap + pos] = make_key(skey, (uint32_t)i);
+            }
+        }
+    }
+}
+
+void launch_hist_compact(const float* d_scores, uint64_t score_ld, uint64_t n, int nq, int metric,
+                         const uint32_t* d_hist, int hist_bits, uint32_t kp, uint64_t* d_keys,
+                         uint32_t cap, uint32_t* d_cnt, uint32_t* d_status, hipStream_t s) {
+    dim3 grid((unsigned)((n + kCompactSlice - 1) / kCompactSlice), nq);
+    if (metric == M_COSINE)
+        hist_compact_kernel<M_COSINE><<<grid, 256, 0, s>>>(d_scores, score_ld, n, d_hist, hist_bits, kp, d_keys, cap, d_cnt, d_status);
+    else
+        hist_compact_kernel<M_L2><<<grid, 256, 0, s>>>(d_scores, score_ld, n, d_hist, hist_bits, kp, d_keys, cap, d_cnt, d_status);
 }
 
 // ------------------------------------------------------------------ candidate lists (MFMA path)
@@ -138,32 +259,46 @@ __global__ __launch_bounds__(kSortThreads) void list_compact_kernel(
     const uint32_t c = counts[q];
     const uint32_t n = c < cap ? c : cap;
     uint2* l = lists + (uint64_t)q * cap;
-    const uint32_t np2 = pow2_ceil(n < 2 ? 2 : n);
-    for (uint32_t i = threadIdx.x; i < np2; i += kSortThreads) {
-        uint64_t key = 0;
-        if (i < n) {
+    const uint64_t* sorted;
+    if (n <= kRankSortMax) {
+        for (uint32_t i = threadIdx.x; i < n; i += kSortThreads) {
             const uint2 e = l[i];
-            key = make_key(score_key_rt(__uint_as_float(e.x), metric), e.y);
+            skeys[i] = make_key(score_key_rt(__uint_as_float(e.x), metric), e.y);
         }
-        skeys[i] = key;
+        __syncthreads();
+        rank_sort_desc(skeys, skeys + kRankSortMax, n);
+        sorted = skeys + kRankSortMax;
+    } else {
+        const uint32_t np2 = pow2_ceil(n);
+        for (uint32_t i = threadIdx.x; i < np2; i += kSortThreads) {
+            uint64_t key = 0;
+            if (i < n) {
+                const uint2 e = l[i];
+                key = make_key(score_key_rt(__uint_as_float(e.x), metric), e.y);
+            }
+            skeys[i] = key;
+        }
+        __syncthreads();
+        bitonic_sort_desc(skeys, np2);
+        sorted = skeys;
     }
-    __syncthreads();
-    bitonic_sort_desc(skeys, np2);
     const uint32_t m = n < keep ? n : keep;
     for (uint32_t i = threadIdx.x; i < m; i += kSortThreads) {
-        const uint64_t key = skeys[i];
+        const uint64_t key = sorted[i];
         l[i] = make_uint2(__float_as_uint(key_to_score_rt(key_skey(key), metric)), key_row(key));
     }
     if (threadIdx.x == 0) {
         counts[q] = m;
-        thr[q] = n >= keep ? key_to_score_rt(key_skey(skeys[keep - 1]), metric) : worst_score(metric);
+        thr[q] = n >= keep ? key_to_score_rt(key_skey(sorted[keep - 1]), metric) : worst_score(metric);
         if (c > cap) atomicOr(&status[q], 2u);
     }
 }
 
 void launch_list_compact(uint2* d_lists, uint32_t* d_counts, uint32_t cap, int nq, int metric,
                          uint32_t keep, float* d_thr, uint32_t* d_status, hipStream_t s) {
-    list_compact_kernel<<<nq, kSortThreads, sort_lds_bytes(cap), s>>>(d_lists, d_counts, cap, metric, keep, d_thr, d_status);
+    size_t lds = sort_lds_bytes(cap);
+    if (lds < 2 * kRankSortMax * sizeof(uint64_t)) lds = 2 * kRankSortMax * sizeof(uint64_t);
+    list_compact_kernel<<<nq, kSortThreads, lds, s>>>(d_lists, d_counts, cap, metric, keep, d_thr, d_status);
 }
 
 __global__ __launch_bounds__(256) void list_to_candidates_kernel(
@@ -200,7 +335,8 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
     float* __restrict__ out_scores, uint32_t* __restrict__ status, float* __restrict__ max_err) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
     const uint32_t q = blockIdx.x;
-    const uint32_t np2 = pow2_ceil(kp < 2 ? 2 : kp);
+    const bool small = kp <= kRankSortMax;
+    const uint32_t np2 = small ? kp : pow2_ceil(kp);
     float err = 0.0f;
     for (uint32_t i = threadIdx.x; i < np2; i += kSortThreads) {
         uint64_t key = 0;
@@ -218,9 +354,16 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
     for (int o = 32; o > 0; o >>= 1) err = __builtin_fmaxf(err, __shfl_xor(err, o));
     if ((threadIdx.x & 63) == 0 && err > 0.0f) atomicMax((uint32_t*)max_err, __float_as_uint(err));
     __syncthreads();
-    bitonic_sort_desc(skeys, np2);
+    const uint64_t* sorted;
+    if (small) {
+        rank_sort_desc(skeys, skeys + kRankSortMax, np2);
+        sorted = skeys + kRankSortMax;
+    } else {
+        bitonic_sort_desc(skeys, np2);
+        sorted = skeys;
+    }
     for (uint32_t i = threadIdx.x; i < k; i += kSortThreads) {
-        const uint64_t key = i < np2 ? skeys[i] : 0ull;
+        const uint64_t key = i < np2 ? sorted[i] : 0ull;
         out_ids[(uint64_t)q * k + i] = key ? (uint64_t)key_row(key) + id_offset : UINT64_MAX;
         out_scores[(uint64_t)q * k + i] = key ? key_to_score_rt(key_skey(key), metric) : __uint_as_float(kScoreNoneBits);
     }
@@ -230,7 +373,7 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
         if (t == worst_score(metric)) {
             ok = true;  // every row of the shard was a candidate
         } else {
-            const uint64_t kk = (k >= 1 && k <= np2) ? skeys[k - 1] : 0ull;
+            const uint64_t kk = (k >= 1 && k <= np2) ? sorted[k - 1] : 0ull;
             if (!kk) {
                 ok = false;  // fewer than k candidates although rows were left out
             } else {
@@ -250,7 +393,9 @@ void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
                        float* d_max_err, hipStream_t s) {
     (void)nrows_total;
     if (!nq) return;
-    final_topk_kernel<<<nq, kSortThreads, sort_lds_bytes(kp), s>>>(d_cand_rows, d_cand_fast, d_cand_canon, d_T, kp, k, metric, id_offset, eps_abs, eps_rel, d_out_ids, d_out_scores, d_status, d_max_err);
+    size_t lds = sort_lds_bytes(kp);
+    if (lds < 2 * kRankSortMax * sizeof(uint64_t)) lds = 2 * kRankSortMax * sizeof(uint64_t);
+    final_topk_kernel<<<nq, kSortThreads, lds, s>>>(d_cand_rows, d_cand_fast, d_cand_canon, d_T, kp, k, metric, id_offset, eps_abs, eps_rel, d_out_ids, d_out_scores, d_status, d_max_err);
 }
 
 // ------------------------------------------------------------------ exact path output

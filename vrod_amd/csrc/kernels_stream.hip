@@ -56,6 +56,11 @@ __device__ __forceinline__ float unit_accumulate(float acc, const typename Unit<
     return acc;
 }
 
+// Histogram resolution of the fused first radix pass: the top HB bits of the order-preserving
+// score key (sign, exponent, leading mantissa bits).  Smaller for more queries (LDS).
+template <int NQ> struct StreamHist { static constexpr int HB = NQ <= 2 ? 12 : (NQ == 4 ? 11 : 10); };
+int stream_hist_bits(int nq_pad) { return nq_pad <= 2 ? 12 : (nq_pad == 4 ? 11 : 10); }
+
 // IT > 0: loads per lane per row known at compile time, UNROLL row-steps in flight.
 // IT == 0: runtime `it` (any ld), one row-step at a time.
 template <typename T, int METRIC, int NQ, int IT, int UNROLL>
@@ -64,12 +69,17 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const T* __restrict__ 
                                                           const float* __restrict__ q,
                                                           float* __restrict__ scores,
                                                           uint64_t score_ld, int lpr_log2,
-                                                          int it_rt) {
+                                                          int it_rt, uint32_t* __restrict__ ghist,
+                                                          uint32_t kp) {
     typedef typename Unit<T>::vec vec_t;
     constexpr int EPU = Unit<T>::EPU;
-    extern __shared__ __attribute__((aligned(16))) float q_lds[];  // [NQ][ld]
+    constexpr int HB = StreamHist<NQ>::HB;          // histogram bits of the score key
+    constexpr int NBINS = 1 << HB;
+    extern __shared__ __attribute__((aligned(16))) float q_lds[];  // [NQ][ld] then hist [NQ][NBINS]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(q_lds + (size_t)NQ * ld);
 
     for (uint32_t i = threadIdx.x; i < (uint32_t)NQ * ld; i += blockDim.x) q_lds[i] = q[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NQ * NBINS; i += blockDim.x) hist[i] = 0u;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -147,23 +157,48 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const T* __restrict__ 
         const uint64_t orow = base + (uint64_t)pos0 * R + grp;
         if (orow < nrows) {
 #pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) scores[(uint64_t)qi * score_ld + orow] = keep[qi];
+            for (int qi = 0; qi < NQ; ++qi) {
+                scores[(uint64_t)qi * score_ld + orow] = keep[qi];
+                atomicAdd(&hist[qi * NBINS + (score_key<METRIC>(keep[qi]) >> (32 - HB))], 1u);
+            }
         }
+    }
+
+    // ---- publish this block's histogram, top bins only.  The global kp-th best score is at
+    // least as good as this block's own kp-th best, so bins below the block's kp-th bin can
+    // never hold the global threshold: only bins >= that bin are added to the global
+    // histogram (a few bins instead of every non-empty one -> few contended atomics).
+    __syncthreads();
+    uint32_t* ctl = hist + NQ * NBINS;  // 8 words
+    constexpr int BPT = NBINS / 256;
+#pragma unroll 1
+    for (int qi = 0; qi < NQ; ++qi) {
+        const uint32_t* h = hist + qi * NBINS;
+        block_find_cut_bin(h, NBINS, kp, ctl);
+        const int cb = (int)ctl[4];
+        const int top = NBINS - 1 - (int)threadIdx.x * BPT;
+#pragma unroll
+        for (int b = 0; b < BPT; ++b) {
+            const int bin = top - b;
+            const uint32_t c = h[bin];
+            if (bin >= cb && c) atomicAdd(&ghist[qi * NBINS + bin], c);
+        }
+        __syncthreads();
     }
 }
 
 template <typename T, int METRIC, int NQ>
 static void dispatch_it(const T* corpus, uint32_t ld, uint64_t nrows, const float* q, float* scores,
-                        uint64_t score_ld, int num_blocks, hipStream_t s) {
+                        uint64_t score_ld, int num_blocks, uint32_t* ghist, uint32_t kp, hipStream_t s) {
     constexpr int EPU = Unit<T>::EPU;
     const uint32_t upr = ld / EPU;  // ld is a multiple of 32 (f32) / 64 (bf16): upr % 8 == 0
     int lpr_log2 = 6;
     while ((upr & ((1u << lpr_log2) - 1)) != 0) --lpr_log2;
     const int it = (int)(upr >> lpr_log2);
-    const size_t lds = (size_t)NQ * ld * sizeof(float);
+    const size_t lds = (size_t)NQ * ld * sizeof(float) + (size_t)NQ * (sizeof(uint32_t) << StreamHist<NQ>::HB) + 32;
 #define VROD_LAUNCH(ITV, UNR)                                                                   \
     scan_stream_kernel<T, METRIC, NQ, ITV, UNR><<<num_blocks, 256, lds, s>>>(                   \
-        corpus, ld, nrows, q, scores, score_ld, lpr_log2, it)
+        corpus, ld, nrows, q, scores, score_ld, lpr_log2, it, ghist, kp)
     switch (it) {
         case 1: VROD_LAUNCH(1, 8); break;
         case 2: VROD_LAUNCH(2, 4); break;
@@ -177,29 +212,30 @@ static void dispatch_it(const T* corpus, uint32_t ld, uint64_t nrows, const floa
 
 template <typename T, int METRIC>
 static void dispatch_nq(const T* corpus, uint32_t ld, uint64_t nrows, const float* q, int nq_pad,
-                        float* scores, uint64_t score_ld, int num_blocks, hipStream_t s) {
+                        float* scores, uint64_t score_ld, int num_blocks, uint32_t* ghist, uint32_t kp,
+                        hipStream_t s) {
     switch (nq_pad) {
-        case 1: dispatch_it<T, METRIC, 1>(corpus, ld, nrows, q, scores, score_ld, num_blocks, s); break;
-        case 2: dispatch_it<T, METRIC, 2>(corpus, ld, nrows, q, scores, score_ld, num_blocks, s); break;
-        case 4: dispatch_it<T, METRIC, 4>(corpus, ld, nrows, q, scores, score_ld, num_blocks, s); break;
-        default: dispatch_it<T, METRIC, 8>(corpus, ld, nrows, q, scores, score_ld, num_blocks, s); break;
+        case 1: dispatch_it<T, METRIC, 1>(corpus, ld, nrows, q, scores, score_ld, num_blocks, ghist, kp, s); break;
+        case 2: dispatch_it<T, METRIC, 2>(corpus, ld, nrows, q, scores, score_ld, num_blocks, ghist, kp, s); break;
+        case 4: dispatch_it<T, METRIC, 4>(corpus, ld, nrows, q, scores, score_ld, num_blocks, ghist, kp, s); break;
+        default: dispatch_it<T, METRIC, 8>(corpus, ld, nrows, q, scores, score_ld, num_blocks, ghist, kp, s); break;
     }
 }
 
 void launch_scan_stream(const void* d_corpus, int dtype, int metric, uint32_t ld, uint64_t nrows,
                         const float* d_q, int nq_pad, float* d_scores, uint64_t score_ld,
-                        hipStream_t s) {
+                        uint32_t* d_hist, uint32_t kp, hipStream_t s) {
     if (!nrows) return;
     // 64 rows per wave step, 4 waves per block; ~8 blocks per CU keeps >100 KB in flight per CU
     uint64_t blocks = (nrows + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     const int nb = (int)blocks;
     if (dtype == DT_BF16) {
-        if (metric == M_COSINE) dispatch_nq<bf16_t, M_COSINE>((const bf16_t*)d_corpus, ld, nrows, d_q, nq_pad, d_scores, score_ld, nb, s);
-        else dispatch_nq<bf16_t, M_L2>((const bf16_t*)d_corpus, ld, nrows, d_q, nq_pad, d_scores, score_ld, nb, s);
+        if (metric == M_COSINE) dispatch_nq<bf16_t, M_COSINE>((const bf16_t*)d_corpus, ld, nrows, d_q, nq_pad, d_scores, score_ld, nb, d_hist, kp, s);
+        else dispatch_nq<bf16_t, M_L2>((const bf16_t*)d_corpus, ld, nrows, d_q, nq_pad, d_scores, score_ld, nb, d_hist, kp, s);
     } else {
-        if (metric == M_COSINE) dispatch_nq<float, M_COSINE>((const float*)d_corpus, ld, nrows, d_q, nq_pad, d_scores, score_ld, nb, s);
-        else dispatch_nq<float, M_L2>((const float*)d_corpus, ld, nrows, d_q, nq_pad, d_scores, score_ld, nb, s);
+        if (metric == M_COSINE) dispatch_nq<float, M_COSINE>((const float*)d_corpus, ld, nrows, d_q, nq_pad, d_scores, score_ld, nb, d_hist, kp, s);
+        else dispatch_nq<float, M_L2>((const float*)d_corpus, ld, nrows, d_q, nq_pad, d_scores, score_ld, nb, d_hist, kp, s);
     }
 }
 

@@ -68,6 +68,38 @@ __device__ inline uint64_t make_key(uint32_t skey, uint32_t row) {
 __device__ inline uint32_t key_row(uint64_t key) { return ~(uint32_t)(key & 0xFFFFFFFFu); }
 __device__ inline uint32_t key_skey(uint64_t key) { return (uint32_t)(key >> 32); }
 
+// ---- radix-select helper: a 256-thread block finds the histogram bin in which the running
+// count, taken from the TOP bin downwards, first reaches kp.  h has nbins (multiple of 256)
+// counters, ctl is 8 words of LDS.  On return ctl[4] = that bin (0 if the total is < kp) and
+// ctl[5] = the count of elements in that bin and all better ones.  Ends with a barrier.
+__device__ inline void block_find_cut_bin(const uint32_t* h, int nbins, uint32_t kp, uint32_t* ctl) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bpt = nbins >> 8;
+    const int top = nbins - 1 - tid * bpt;  // thread t owns bins top, top-1, ..., top-bpt+1
+    uint32_t mine = 0;
+    for (int b = 0; b < bpt; ++b) mine += h[top - b];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) ctl[wave] = incl;
+    if (tid == 0) { ctl[4] = 0u; ctl[5] = 0u; }
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (int w = 0; w < wave; ++w) before += ctl[w];
+    if (before < kp && before + mine >= kp) {
+        uint32_t c = before;
+        int b = 0;
+        for (; b < bpt; ++b) { c += h[top - b]; if (c >= kp) break; }
+        ctl[4] = (uint32_t)(top - b);
+        ctl[5] = c;
+    }
+    if (tid == 255 && before + mine < kp) ctl[5] = before + mine;  // short: everything counts
+    __syncthreads();
+}
+
 // "worst possible" fast score per metric (threshold meaning: nothing is filtered)
 __host__ __device__ inline float worst_score(int metric) {
     return metric == M_COSINE ? -__builtin_huge_valf() : __builtin_huge_valf();

@@ -95,7 +95,7 @@ struct vrod_index {
     vrod_search_stats stats{};
 
     // workspaces
-    DevBuf raw_stage, nrm_ws, q_raw, q_f32, q_lp, scores, keys_a, keys_b, lists, small;
+    DevBuf raw_stage, nrm_ws, q_raw, q_f32, q_lp, scores, keys_a, keys_b, lists, small, hist;
     DevBuf cand_rows, cand_fast, cand_canon, out_ids, out_scores;
     uint32_t* flags = nullptr;  // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits
     std::vector<hipEvent_t> ev;
@@ -338,22 +338,31 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         else { eps_rel = 4.f * (idx->dim + 2) * u; eps_abs = 1e-30f; }
         const uint64_t score_ld = round_up(N, 64);
         VROD_TRY(idx->scores.ensure((size_t)8 * score_ld * 4));
+        // radix select, pass 1 fused into the scan: [8][<=4096] bin counters + 8 key counters
+        const size_t hist_words = 8 * 4096 + 8;
+        VROD_TRY(idx->hist.ensure(hist_words * 4));
+        VROD_TRY(idx->keys_a.ensure((size_t)8 * kSelectChunk * 8));
+        uint32_t* d_hist = idx->hist.as<uint32_t>();
+        uint32_t* d_cnt = d_hist + 8 * 4096;
         for (uint32_t q0 = 0; q0 < nq; q0 += 8) {
             const int nqc = (int)std::min<uint32_t>(8, nq - q0);
             int nqp = 1;
             while (nqp < nqc) nqp <<= 1;
+            HIP_TRY(hipMemsetAsync(d_hist, 0, hist_words * 4, s));
             const size_t a = tm.mark();
             launch_scan_stream(idx->corpus, idx->dtype, idx->metric, idx->ld, N,
-                               idx->q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, idx->scores.as<float>(), score_ld, s);
+                               idx->q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, idx->scores.as<float>(), score_ld,
+                               d_hist, kp, s);
             const size_t b = tm.mark();
             tm.scan_pairs.push_back({a, b});
             st.scan_launches++;
             st.scan_bytes += (double)N * row_bytes_alg;
             st.scan_flops += 2.0 * nqc * (double)N * idx->dim;
-            const uint64_t* keys; uint64_t kld, kn;
-            VROD_TRY(select_chain(idx, idx->scores.as<float>(), score_ld, N, nqc, kp, &keys, &kld, &kn));
-            launch_keys_to_candidates(keys, kld, kn, nqc, idx->metric, kp, idx->cand_rows.as<uint32_t>() + (size_t)q0 * kp,
-                                      idx->cand_fast.as<float>() + (size_t)q0 * kp, d_T + q0, s);
+            launch_hist_compact(idx->scores.as<float>(), score_ld, N, nqc, idx->metric, d_hist, stream_hist_bits(nqp), kp,
+                                idx->keys_a.as<uint64_t>(), kSelectChunk, d_cnt, d_status + q0, s);
+            launch_keys_to_candidates(idx->keys_a.as<uint64_t>(), kSelectChunk, kSelectChunk, nqc, idx->metric, kp,
+                                      idx->cand_rows.as<uint32_t>() + (size_t)q0 * kp, idx->cand_fast.as<float>() + (size_t)q0 * kp,
+                                      d_T + q0, d_cnt, s);
         }
         HIP_TRY(hipGetLastError());
     } else if (path == VROD_PATH_MFMA) {
@@ -494,7 +503,7 @@ int vrod_index_destroy(vrod_index* idx) {
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     for (DevBuf* b : {&idx->raw_stage, &idx->nrm_ws, &idx->q_raw, &idx->q_f32, &idx->q_lp, &idx->scores, &idx->keys_a,
-                      &idx->keys_b, &idx->lists, &idx->small, &idx->cand_rows, &idx->cand_fast, &idx->cand_canon,
+                      &idx->keys_b, &idx->lists, &idx->small, &idx->hist, &idx->cand_rows, &idx->cand_fast, &idx->cand_canon,
                       &idx->out_ids, &idx->out_scores})
         b->release();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);

@@ -18,9 +18,19 @@ void launch_rows_get(const void* d_rows, int dtype, uint64_t n, uint32_t dim, ui
 
 // ---- kernels_stream.hip : Q <= 8 HBM-bound scan, writes fast scores [nq_pad][score_ld]
 // nq_pad in {1,2,4,8}; d_q is [nq_pad][ld] prepared fp32 (zero rows for padding).
+// Also accumulates, per query, a histogram of the top stream_hist_bits(nq_pad) bits of the
+// score keys into d_hist [nq_pad][1 << bits] (must be zeroed by the caller): only the bins at
+// or above each block's own kp-th best are published, which is all the global select needs.
 void launch_scan_stream(const void* d_corpus, int dtype, int metric, uint32_t ld, uint64_t nrows,
                         const float* d_q, int nq_pad, float* d_scores, uint64_t score_ld,
-                        hipStream_t s);
+                        uint32_t* d_hist, uint32_t kp, hipStream_t s);
+int stream_hist_bits(int nq_pad);
+// Radix-select step 2: find the histogram bin holding the kp-th best score, then compact
+// every row whose key falls in that bin or a better one into d_keys[q][...] (composite keys,
+// unordered), counting into d_cnt[q].  More than `cap` such rows -> d_status[q] bit 1.
+void launch_hist_compact(const float* d_scores, uint64_t score_ld, uint64_t n, int nq, int metric,
+                         const uint32_t* d_hist, int hist_bits, uint32_t kp, uint64_t* d_keys,
+                         uint32_t cap, uint32_t* d_cnt, uint32_t* d_status, hipStream_t s);
 
 // ---- kernels_select.hip
 // Level 0: fast scores (implicit ids = column index) -> per-chunk top-kp composite keys.
@@ -35,9 +45,10 @@ uint64_t launch_select_from_keys(const uint64_t* d_in, uint64_t in_ld, uint64_t 
 // Final step of a select chain: keys (n <= kSelectChunk per query, sorted or not) ->
 // candidate rows [nq][kp] (sorted best first, ~0u padding) and T[q] = fast score of the
 // kp-th candidate (worst score if fewer than kp candidates exist: nothing was left out).
+// d_cnt != nullptr: the number of keys of query q is min(d_cnt[q], n) (device-side count).
 void launch_keys_to_candidates(const uint64_t* d_keys, uint64_t key_ld, uint64_t n, int nq,
                                int metric, uint32_t kp, uint32_t* d_cand_rows, float* d_cand_fast,
-                               float* d_T, hipStream_t s);
+                               float* d_T, const uint32_t* d_cnt, hipStream_t s);
 
 // MFMA path: per-query candidate lists {fast score bits, row} appended by the scan kernel.
 // Sort each list, keep the best `keep`, write thr[q] = keep-th fast score (worst if short),
