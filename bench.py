@@ -115,9 +115,9 @@ def cpu_baseline(wl, va, torch, dev, n_total):
     raw = O.synth_rows(CORPUS_SEED, 0, ns, dim, threads=cores)
     corpus = O.prepare(raw, DT[wl["dtype"]], ME[wl["metric"]], threads=cores)
     del raw
-    # size the query samples for ~10 s (all cores) and ~6 s (one thread) at ~1e9 mul-add/s/thread
-    q_all = int(max(2, min(64, 10.0 * 1e9 * cores / (ns * dim))))
-    q_one = int(max(1, min(8, 6.0 * 1e9 / (ns * dim))))
+    # size the query samples for ~12 s (all cores) and ~6 s (one thread) at ~2.5e9 mul-add/s/thread
+    q_all = int(max(2, min(512, 12.0 * 2.5e9 * cores / (ns * dim))))
+    q_one = int(max(1, min(16, 6.0 * 2.5e9 / (ns * dim))))
     rq = O.synth_rows(QUERY_SEED, 0, q_all, dim)
     pq = O.prepare(rq, DT[wl["dtype"]], ME[wl["metric"]])
     gen_s = time.time() - t
@@ -215,7 +215,7 @@ def main():
         else:
             achieved = acc["scan_flops"] / (acc["scan_ms"] * 1e-3) / 1e12 if acc["scan_ms"] else 0.0
             peak, unit = PEAK["mfma_bf16" if wl["dtype"] == "bf16" else "mfma_f32"]
-            kernel = "scan_mfma_kernel"
+            kernel = "scan_mfma_phased_kernel"
             per_launch = acc["scan_flops"] / max(acc["launches"], 1)
             work_key = "algorithmic_flops_per_launch"
         traffic = None
