@@ -204,3 +204,44 @@ def test_merge_topk_device_matches_oracle(va, oracle):
     # and against the oracle's own merge of the oracle's own shard results
     mi2, ms2 = oracle.merge_topk(np.stack(ids_l), np.stack(sc_l), 0)
     assert_same(mi2, ms2, oi, osc, "oracle merge")
+
+
+# ---------------------------------------------------------------- scale / structure cases
+def test_mfma_path_splits_launches_past_2pow24_rows(va, oracle):
+    """Rows are addressed relative to a launch's first tile with 24 bits: a 17M-row shard needs
+    two launches per stage.  64-d bf16 keeps it at 2 GB; oracle on 8 threads."""
+    n, dim, nq, k = (1 << 24) + 300_001, 64, 12, 10
+    with va.Index(dim, "bf16", "cosine") as ix:
+        ix.add_synthetic(1, 0, n)
+        ix.set_path(va.PATH_MFMA)
+        rq = oracle.synth_rows(2, 0, nq, dim)
+        ids, sc = ix.search(rq, k)
+        st = ix.last_stats()
+    raw = oracle.synth_rows(1, 0, n, dim, threads=8)
+    oi, osc = oracle.search(raw, rq, k, 1, 0, threads=8)
+    assert_same(ids, sc, oi, osc, "17M rows")
+    assert st["fallback_queries"] == 0 and st["scan_launches"] >= 4
+
+
+@pytest.mark.parametrize("dtype,metric", [("bf16", "l2"), ("f32", "l2"), ("bf16", "cosine")])
+def test_mfma_padded_batch_300k_rows(va, oracle, dtype, metric):
+    """Batch of 300 pads to 512 query columns; unnormalised rows exercise the L2 norm expansion."""
+    rng = np.random.default_rng(21)
+    raw = (oracle.synth_rows(1, 0, 300_000, 128, threads=8) * rng.uniform(0.5, 2.0, (300_000, 1))).astype(np.float32)
+    rq = (oracle.synth_rows(2, 0, 300, 128) * rng.uniform(0.5, 2.0, (300, 1))).astype(np.float32)
+    with va.Index(128, dtype, metric) as ix:
+        ix.add(raw)
+        ids, sc = ix.search(rq, 10)
+        st = ix.last_stats()
+    oi, osc = oracle.search(raw, rq, 10, DT[dtype], ME[metric], threads=8)
+    assert_same(ids, sc, oi, osc, f"{dtype}/{metric} 300x300k")
+    assert st["path"] == 2 and st["max_fast_err"] <= st["eps_bound"]
+
+
+def test_synthetic_add_equals_host_add(va, oracle):
+    """vrod_index_add_synthetic (generated in HBM) == vrod_index_add of the oracle's stream."""
+    raw = oracle.synth_rows(1, 1000, 5000, 96)
+    with va.Index(96, "bf16", "cosine") as a, va.Index(96, "bf16", "cosine") as b:
+        a.add_synthetic(1, 1000, 5000)
+        b.add(raw)
+        assert np.array_equal(bits(a.get_rows(0, 5000)), bits(b.get_rows(0, 5000)))

@@ -83,6 +83,8 @@ struct MfmaKernelArgs {
     uint32_t nstrips;       // corpus strips (8 * strips_per_xcd)
     uint32_t strips_per_xcd;
     uint32_t slots;         // work-groups per XCD label (gridDim.x / 8)
+    float* dense_out;       // DENSE launches: fast scores [nq_pad][dense_ld], column = row - row_lo
+    uint32_t dense_ld;
 };
 
 template <int METRIC>
@@ -133,6 +135,9 @@ template <int METRIC>
 __device__ __forceinline__ void filter_tile(const MfmaKernelArgs& a, f32x4 (&acc)[8][4], const float (&thr)[4],
                                             const float (&qn2)[4], uint32_t row_w, uint32_t ql0, uint32_t qb,
                                             uint32_t rel_base, uint2* log, uint32_t* log_cnt) {
+    // LDS byte addresses of the log and its counter (for the inline-asm appends)
+    const uint32_t lds_log_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log;
+    const uint32_t lds_cnt_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log_cnt;
     bool hit[4];
     bool any = false;
     // L2: fast distance = |q|^2 + |x|^2 - 2 q.x ; the row norms are re-read per 16-row block
@@ -171,21 +176,61 @@ __device__ __forceinline__ void filter_tile(const MfmaKernelArgs& a, f32x4 (&acc
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 if (!__any(hit[n])) continue;
+                // one test per 16x16 tile (4 scores per lane) before the 4 predicated append sites
+                const float s0 = score(xv, m, n, 0), s1 = score(xv, m, n, 1), s2 = score(xv, m, n, 2), s3 = score(xv, m, n, 3);
+                const float tb = METRIC == M_COSINE ? __builtin_fmaxf(__builtin_fmaxf(s0, s1), __builtin_fmaxf(s2, s3))
+                                                    : __builtin_fminf(__builtin_fminf(s0, s1), __builtin_fminf(s2, s3));
+                if (!__any(better<METRIC>(tb, thr[n]))) continue;
                 const uint32_t ql = ql0 + n * 16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float s = score(xv, m, n, r);
+                    const float s = r == 0 ? s0 : r == 1 ? s1 : r == 2 ? s2 : s3;
                     const uint32_t row = row_w + m * 16 + r;
                     if (better<METRIC>(s, thr[n]) && row >= a.row_lo && row < a.row_end) {
-                        const uint32_t pos = atomicAdd(&log_cnt[0], 1u);
+                        // LDS log append in inline asm: as compiler-visible LDS accesses these would
+                        // each be preceded by s_waitcnt vmcnt(0) (they may alias the LDS-DMA
+                        // destination), draining the staging pipeline on every hit.
+                        uint32_t pos;
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=v"(pos) : "v"(lds_cnt_addr), "v"(1u) : "memory");
                         if (pos < (uint32_t)kLogCap) {
-                            log[pos] = make_uint2(__float_as_uint(s), (ql << 24) | (row - rel_base));
-                            if (pos >= (uint32_t)(kLogCap / 2)) log_cnt[3] = 1u;  // sticky "flush due"
+                            const uint64_t e = ((uint64_t)((ql << 24) | (row - rel_base)) << 32) | __float_as_uint(s);
+                            asm volatile("ds_write_b64 %0, %1" :: "v"(lds_log_addr + pos * 8u), "v"(e) : "memory");
+                            if (pos >= (uint32_t)(kLogCap / 2))  // sticky "flush due"
+                                asm volatile("ds_write_b32 %0, %1" :: "v"(lds_cnt_addr + 12u), "v"(1u) : "memory");
                         } else {
                             global_append(a, qb * kBN + ql, __float_as_uint(s), row);
                         }
                     }
                 }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm LDS writes above are not tracked by the compiler
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Dense epilogue (sample pass): write the wave's 128 x 64 fast scores instead of filtering.
+// A lane holds 4 consecutive rows of one query column per 16x16 tile -> one 16-B store each.
+template <int METRIC>
+__device__ __forceinline__ void dense_store_tile(const MfmaKernelArgs& a, f32x4 (&acc)[8][4], const float (&qn2)[4],
+                                                 uint32_t row_w, uint32_t gq0) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const uint32_t row = row_w + m * 16;
+        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (METRIC == M_L2) xv = *reinterpret_cast<const f32x4*>(a.xnorm2 + row);
+        if (row - a.row_lo < a.dense_ld) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                f32x4 sc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sc[r] = METRIC == M_COSINE ? acc[m][n][r] : __builtin_fmaf(-2.0f, acc[m][n][r], xv[r] + qn2[n]);
+                *reinterpret_cast<f32x4*>(a.dense_out + (uint64_t)(gq0 + n * 16) * a.dense_ld + (row - a.row_lo)) = sc;
             }
         }
     }
@@ -332,7 +377,8 @@ __global__ __launch_bounds__(512) void scan_mfma_kernel(const MfmaKernelArgs a) 
 // to the ds_reads (an LDS-DMA issue is ~2-3x cheaper among MFMAs than beside LDS reads, and
 // the load segment is the one that must not outlast the partner's 256-cycle MFMA segment).
 // The unit issue order per wave is unchanged, so the counted wait is vmcnt(4 - GP).
-template <typename T, int METRIC, int GP>
+// DENSE: the epilogue stores every score (sample pass) instead of filtering against thresholds.
+template <typename T, int METRIC, int GP, bool DENSE>
 __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* log_cnt = reinterpret_cast<uint32_t*>(lds + kLdsCtl);  // [0] count [3] flush due
@@ -494,7 +540,10 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
             VROD_COMPUTE(1, 0, A, 8)
             if (kt == KT - 1) {
                 const uint32_t tile = t0 + it / KT;
-                filter_tile<METRIC>(a, acc, thr, qn2, tile * kBM + wr * 128 + fg * 4, wc * 64 + fr, qb, rel_base, log, log_cnt);
+                if constexpr (DENSE)
+                    dense_store_tile<METRIC>(a, acc, qn2, tile * kBM + wr * 128 + fg * 4, qb * kBN + wc * 64 + fr);
+                else
+                    filter_tile<METRIC>(a, acc, thr, qn2, tile * kBM + wr * 128 + fg * 4, wc * 64 + fr, qb, rel_base, log, log_cnt);
             }
             VROD_BARRIER();
 
@@ -542,6 +591,8 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     a.ntiles = (h.row_end + kBM - 1) / kBM - a.tile_first;
     a.row_lo = h.row_begin;
     a.row_end = h.row_end;
+    a.dense_out = h.dense_out;
+    a.dense_ld = h.dense_ld;
     int grid = num_cus / 8 * 8;
     if (grid < 8) grid = 8;
     a.slots = grid / 8;
@@ -559,22 +610,23 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
         KERNEL<TT, MM><<<grid, 512, kLdsTotal, s>>>(a);                                                     \
     } while (0)
     static const int gp = [] { const char* e = getenv("VROD_MFMA_GP"); return e ? atoi(e) : 0; }();
-#define VROD_MFMA_P(TT, MM, GPV)                                                                            \
+#define VROD_MFMA_P(TT, MM, GPV, DN)                                                                            \
     do {                                                                                                    \
         static bool attr_set = false;                                                                       \
         if (!attr_set) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)scan_mfma_phased_kernel<TT, MM, GPV>,                    \
+            (void)hipFuncSetAttribute((const void*)scan_mfma_phased_kernel<TT, MM, GPV, DN>,                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);               \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        scan_mfma_phased_kernel<TT, MM, GPV><<<grid, 512, kLdsTotal, s>>>(a);                               \
+        scan_mfma_phased_kernel<TT, MM, GPV, DN><<<grid, 512, kLdsTotal, s>>>(a);                               \
     } while (0)
 #define VROD_MFMA_BOTH(TT, MM)                                                                              \
     do {                                                                                                    \
-        if (simple) VROD_MFMA(scan_mfma_kernel, TT, MM);                                                    \
-        else if (gp == 1) VROD_MFMA_P(TT, MM, 1);                                                           \
-        else if (gp == 2) VROD_MFMA_P(TT, MM, 2);                                                           \
-        else VROD_MFMA_P(TT, MM, 0);                                                                        \
+        if (h.dense_out) VROD_MFMA_P(TT, MM, 0, true);                                                      \
+        else if (simple) VROD_MFMA(scan_mfma_kernel, TT, MM);                                               \
+        else if (gp == 1) VROD_MFMA_P(TT, MM, 1, false);                                                    \
+        else if (gp == 2) VROD_MFMA_P(TT, MM, 2, false);                                                    \
+        else VROD_MFMA_P(TT, MM, 0, false);                                                                 \
     } while (0)
     if (dtype == DT_BF16) { if (h.metric == M_COSINE) VROD_MFMA_BOTH(bf16_t, M_COSINE); else VROD_MFMA_BOTH(bf16_t, M_L2); }
     else { if (h.metric == M_COSINE) VROD_MFMA_BOTH(float, M_COSINE); else VROD_MFMA_BOTH(float, M_L2); }

@@ -134,6 +134,64 @@ __global__ __launch_bounds__(256) void rows_get_kernel(const T* __restrict__ row
     }
 }
 
+// ------------------------------------------------------------------ query preparation, one launch
+// One block per (padded) query: stage the row in LDS, thread 0 walks it left to right in fp64
+// (the spec's order), every thread then writes the normalised / bf16-rounded row (zero padding
+// to ld, zero rows for q >= nq) and the block reduces the fast squared norm.
+template <bool NORMALISE>
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ in, uint32_t nq, uint32_t dim,
+                                                           uint32_t ld, int round_bf16, float* __restrict__ out_f32,
+                                                           bf16_t* __restrict__ out_bf16, float* __restrict__ qn2,
+                                                           uint32_t* __restrict__ bad_flag,
+                                                           uint32_t* __restrict__ max_bits) {
+    extern __shared__ __attribute__((aligned(16))) float row[];  // [dim]
+    __shared__ double s_nrm;
+    __shared__ float s_part[4];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const bool live = q < nq;
+    bool bad = false;
+    if (live) {
+        for (uint32_t j = tid; j < dim; j += 256) {
+            const float f = in[(uint64_t)q * dim + j];
+            bad |= !(__builtin_fabsf(f) <= 3.4028234663852886e38f);
+            row[j] = f;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double ss = 0.0;
+        if (live && NORMALISE)
+            for (uint32_t j = 0; j < dim; ++j) { const double v = (double)row[j]; ss = __builtin_fma(v, v, ss); }
+        s_nrm = __builtin_sqrt(ss);
+    }
+    __syncthreads();
+    const double nrm = s_nrm;
+    float fs = 0.0f;
+    for (uint32_t j = tid; j < ld; j += 256) {
+        float v = 0.0f;
+        if (live && j < dim) {
+            v = row[j];
+            if (NORMALISE) v = nrm == 0.0 ? 0.0f : (float)((double)v / nrm);
+        }
+        if (round_bf16) {
+            const bf16_t h = f32_to_bf16_rne(v);
+            if (out_bf16) out_bf16[(uint64_t)q * ld + j] = h;
+            v = bf16_to_f32(h);
+        }
+        out_f32[(uint64_t)q * ld + j] = v;
+        fs = __builtin_fmaf(v, v, fs);
+    }
+    for (int o = 32; o > 0; o >>= 1) fs += __shfl_xor(fs, o);
+    if ((tid & 63) == 0) s_part[tid >> 6] = fs;
+    __syncthreads();
+    if (tid == 0) {
+        const float t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        qn2[q] = t;
+        if (live) atomicMax(max_bits, __float_as_uint(t));
+    }
+    if (bad) atomicOr(bad_flag, 1u);
+}
+
 // ------------------------------------------------------------------ launchers
 static inline int grid_for(uint64_t work, int block, int cap = 256 * 8) {
     uint64_t g = (work + block - 1) / block;
@@ -163,6 +221,18 @@ void launch_prepare_rows(const float* d_in, uint64_t n, uint32_t dim, uint32_t l
     else
         row_write_kernel<false><<<g, 256, 0, s>>>(d_in, n, dim, ld, d_nrm_ws, rb, d_out_f32,
                                                   (bf16_t*)d_out_bf16);
+}
+
+void launch_prep_queries(const float* d_in, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t ld, int metric,
+                         int dtype, float* d_out_f32, void* d_out_bf16, float* d_qn2, uint32_t* d_bad_flag,
+                         uint32_t* d_max_bits, hipStream_t s) {
+    if (!nq_pad) return;
+    const size_t lds = (size_t)dim * sizeof(float);
+    const int rb = dtype == DT_BF16;
+    if (metric == M_COSINE)
+        prep_queries_kernel<true><<<nq_pad, 256, lds, s>>>(d_in, nq, dim, ld, rb, d_out_f32, (bf16_t*)d_out_bf16, d_qn2, d_bad_flag, d_max_bits);
+    else
+        prep_queries_kernel<false><<<nq_pad, 256, lds, s>>>(d_in, nq, dim, ld, rb, d_out_f32, (bf16_t*)d_out_bf16, d_qn2, d_bad_flag, d_max_bits);
 }
 
 void launch_row_fastnorm(const void* d_rows, int dtype, uint64_t n, uint32_t ld, float* d_xn2,

@@ -23,9 +23,10 @@ constexpr int kSortThreads = 1024;
 // stride j is < S only pairs keys inside one segment, so it needs no block barrier: LDS
 // operations of one wave execute in order, a compiler fence is enough.  Only the log2(W)
 // largest strides of each merge step are block-wide (10 of 91 stages at n = 8192).
+template <uint32_t NT = kSortThreads>
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* __restrict__ a, uint32_t n) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr uint32_t kWaves = kSortThreads / 64;
+    constexpr uint32_t kWaves = NT / 64;
     const uint32_t W = n / 128 < kWaves ? (n / 128 ? n / 128 : 1) : kWaves;  // active waves
     const uint32_t S = n / W;                                                 // keys per segment
     const bool active = wave < W;
@@ -35,7 +36,7 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t* __restrict__ a, uint
             if (j >= S) {
                 // block-wide stage
                 if (dirty_local) { __syncthreads(); dirty_local = false; }
-                for (uint32_t t = tid; t < (n >> 1); t += kSortThreads) {
+                for (uint32_t t = tid; t < (n >> 1); t += NT) {
                     const uint32_t i = 2 * t - (t & (j - 1));
                     const uint32_t l = i + j;
                     const bool up = (i & k) == 0;
@@ -251,54 +252,53 @@ void launch_hist_compact(const float* d_scores, uint64_t score_ld, uint64_t n, i
 
 // ------------------------------------------------------------------ candidate lists (MFMA path)
 // lists[q][cap] of {fast score bits, row}; counts[q] may exceed cap (overflow -> status bit 1).
-__global__ __launch_bounds__(kSortThreads) void list_compact_kernel(
+// One 256-thread block per query with an LDS window of `wsize` keys (2048 = 16 KB when
+// keep <= 1024 -- lists normally hold a few hundred entries -- else 8192): the best `keep` so
+// far stay at the front of the window and the list streams through the rest of it chunk by
+// chunk, so any count <= cap is handled.  Requires keep <= wsize / 2.
+constexpr uint32_t kCompactThreads = 256;
+__global__ __launch_bounds__(kCompactThreads) void list_compact_kernel(
     uint2* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t cap, int metric,
-    uint32_t keep, float* __restrict__ thr, uint32_t* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
-    const uint32_t q = blockIdx.x;
+    uint32_t keep, uint32_t wsize, float* __restrict__ thr, uint32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t win[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t c = counts[q];
     const uint32_t n = c < cap ? c : cap;
     uint2* l = lists + (uint64_t)q * cap;
-    const uint64_t* sorted;
-    if (n <= kRankSortMax) {
-        for (uint32_t i = threadIdx.x; i < n; i += kSortThreads) {
-            const uint2 e = l[i];
-            skeys[i] = make_key(score_key_rt(__uint_as_float(e.x), metric), e.y);
+    const uint32_t kk = keep;
+    uint32_t have = 0;          // sorted best-so-far at win[0..have)
+    uint32_t done = 0;
+    while (done < n) {
+        const uint32_t room = wsize - have;
+        const uint32_t take = n - done < room ? n - done : room;
+        for (uint32_t i = tid; i < take; i += kCompactThreads) {
+            const uint2 e = l[done + i];
+            win[have + i] = make_key(score_key_rt(__uint_as_float(e.x), metric), e.y);
         }
+        const uint32_t m = have + take;
+        const uint32_t np2 = pow2_ceil(m < 2 ? 2 : m);
+        for (uint32_t i = m + tid; i < np2; i += kCompactThreads) win[i] = 0ull;
         __syncthreads();
-        rank_sort_desc(skeys, skeys + kRankSortMax, n);
-        sorted = skeys + kRankSortMax;
-    } else {
-        const uint32_t np2 = pow2_ceil(n);
-        for (uint32_t i = threadIdx.x; i < np2; i += kSortThreads) {
-            uint64_t key = 0;
-            if (i < n) {
-                const uint2 e = l[i];
-                key = make_key(score_key_rt(__uint_as_float(e.x), metric), e.y);
-            }
-            skeys[i] = key;
-        }
+        bitonic_sort_desc<kCompactThreads>(win, np2);
+        have = m < kk ? m : kk;
+        done += take;
         __syncthreads();
-        bitonic_sort_desc(skeys, np2);
-        sorted = skeys;
     }
-    const uint32_t m = n < keep ? n : keep;
-    for (uint32_t i = threadIdx.x; i < m; i += kSortThreads) {
-        const uint64_t key = sorted[i];
+    for (uint32_t i = tid; i < have; i += kCompactThreads) {
+        const uint64_t key = win[i];
         l[i] = make_uint2(__float_as_uint(key_to_score_rt(key_skey(key), metric)), key_row(key));
     }
-    if (threadIdx.x == 0) {
-        counts[q] = m;
-        thr[q] = n >= keep ? key_to_score_rt(key_skey(sorted[keep - 1]), metric) : worst_score(metric);
+    if (tid == 0) {
+        counts[q] = have;
+        if (n >= keep && have >= keep) thr[q] = key_to_score_rt(key_skey(win[keep - 1]), metric);  // else: unchanged
         if (c > cap) atomicOr(&status[q], 2u);
     }
 }
 
 void launch_list_compact(uint2* d_lists, uint32_t* d_counts, uint32_t cap, int nq, int metric,
                          uint32_t keep, float* d_thr, uint32_t* d_status, hipStream_t s) {
-    size_t lds = sort_lds_bytes(cap);
-    if (lds < 2 * kRankSortMax * sizeof(uint64_t)) lds = 2 * kRankSortMax * sizeof(uint64_t);
-    list_compact_kernel<<<nq, kSortThreads, lds, s>>>(d_lists, d_counts, cap, metric, keep, d_thr, d_status);
+    const uint32_t wsize = keep <= 1024 ? 2048u : kSelectChunk;
+    list_compact_kernel<<<nq, kCompactThreads, (size_t)wsize * 8, s>>>(d_lists, d_counts, cap, metric, keep, wsize, d_thr, d_status);
 }
 
 __global__ __launch_bounds__(256) void list_to_candidates_kernel(
@@ -321,6 +321,94 @@ void launch_list_to_candidates(const uint2* d_lists, const uint32_t* d_counts, u
     list_to_candidates_kernel<<<nq, 256, 0, s>>>(d_lists, d_counts, cap, kp, d_cand_rows, d_cand_fast);
 }
 
+// ------------------------------------------------------------------ sample pass: exact j-th best
+// One block per query over its n sample scores (L2-resident).  j is tiny next to n, so:
+//   pass 1: every thread takes the best key of its own strided slice; the j-th largest of
+//           those 256 keys is a LOWER bound L of the answer (they are j distinct elements);
+//   pass 2: the few keys >= L are collected in LDS (expected ~j..3j of them);
+//   then the exact j-th best among them (rank by counting).
+// If more than kSampleListCap keys pass (heavy ties) the block falls back to three radix
+// passes (12 + 12 + 8 bits) with LDS histograms.
+constexpr uint32_t kSampleListCap = 2048;
+template <int METRIC>
+__global__ __launch_bounds__(256) void sample_select_kernel(const float* __restrict__ scores, uint64_t score_ld,
+                                                            uint32_t n, uint32_t j, float* __restrict__ thr) {
+    __shared__ uint32_t hist[4096];   // pass-1 maxima [256] / candidate list [2048] / radix histogram
+    __shared__ uint32_t ctl[8];
+    const float* sc = scores + (uint64_t)blockIdx.x * score_ld;
+    const uint32_t tid = threadIdx.x;
+    if (j <= 256) {
+        uint32_t best = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += 256 * 8) {   // 8 independent loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 256 + tid; v[u] = i < n ? sc[i] : __uint_as_float(kScoreNoneBits); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t k = score_key<METRIC>(v[u]); best = k > best ? k : best; }
+        }
+        hist[tid] = best;
+        if (tid == 0) ctl[6] = 0u;
+        __syncthreads();
+        // rank of my maximum among the 256 (ties by thread id): the one with rank j-1 is L
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < 256; ++t) { const uint32_t o = hist[t]; rank += (o > best) || (o == best && t < tid); }
+        if (rank == j - 1) ctl[7] = best;
+        __syncthreads();
+        const uint32_t L = ctl[7];
+        uint32_t* list = hist + 1024;   // [kSampleListCap]
+        for (uint32_t i0 = 0; i0 < n; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 256 + tid; v[u] = i < n ? sc[i] : __uint_as_float(kScoreNoneBits); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t k = score_key<METRIC>(v[u]);   // NaN padding -> key 0 < L
+                if (k >= L && k != 0u) { const uint32_t p = atomicAdd(&ctl[6], 1u); if (p < kSampleListCap) list[p] = k; }
+            }
+        }
+        __syncthreads();
+        const uint32_t m = ctl[6];
+        if (m <= kSampleListCap) {
+            // exact j-th largest of list[0..m): count keys greater (ties: earlier index first)
+            for (uint32_t i = tid; i < m; i += 256) {
+                const uint32_t mine = list[i];
+                uint32_t r = 0;
+                for (uint32_t t = 0; t < m; ++t) { const uint32_t o = list[t]; r += (o > mine) || (o == mine && t < i); }
+                if (r == j - 1) thr[blockIdx.x] = key_to_score_rt(mine, METRIC);
+            }
+            return;
+        }
+        __syncthreads();
+    }
+    uint32_t prefix = 0, prefix_bits = 0, remaining = j;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        const uint32_t bits = pass == 2 ? 8u : 12u;
+        const uint32_t nb = 1u << bits, shift = 32u - prefix_bits - bits;
+        for (uint32_t i = tid; i < nb; i += 256) hist[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t key = score_key<METRIC>(sc[i]);
+            if (prefix_bits == 0 || (key >> (32u - prefix_bits)) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        block_find_cut_bin(hist, (int)nb, remaining, ctl);
+        const uint32_t cut = ctl[4], cum = ctl[5];
+        remaining -= cum - hist[cut];  // rows in strictly better bins are accounted for
+        prefix = (prefix << bits) | cut;
+        prefix_bits += bits;
+        __syncthreads();
+    }
+    if (tid == 0) thr[blockIdx.x] = key_to_score_rt(prefix, METRIC);
+}
+
+void launch_sample_select(const float* d_scores, uint64_t score_ld, uint32_t n_sample, int nq,
+                          int metric, uint32_t j, float* d_thr, hipStream_t s) {
+    if (!nq) return;
+    if (metric == M_COSINE) sample_select_kernel<M_COSINE><<<nq, 256, 0, s>>>(d_scores, score_ld, n_sample, j, d_thr);
+    else sample_select_kernel<M_L2><<<nq, 256, 0, s>>>(d_scores, score_ld, n_sample, j, d_thr);
+}
+
 // ------------------------------------------------------------------ final ordering + certificate
 // One block per query.  Sort candidates by (canonical score, id); emit the best k.
 // Certificate (DESIGN.md "Exactness certificate"): every row NOT among the candidates has a
@@ -331,7 +419,8 @@ void launch_list_to_candidates(const uint2* d_lists, const uint32_t* d_counts, u
 __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
     const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_fast,
     const float* __restrict__ cand_canon, const float* __restrict__ T, uint32_t kp, uint32_t k,
-    int metric, uint64_t id_offset, float eps_abs, float eps_rel, uint64_t* __restrict__ out_ids,
+    int metric, uint64_t id_offset, int eps_mode, float eps_c, const uint32_t* __restrict__ max_qn2_bits,
+    const uint32_t* __restrict__ max_xn2_bits, uint64_t* __restrict__ out_ids,
     float* __restrict__ out_scores, uint32_t* __restrict__ status, float* __restrict__ max_err) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
     const uint32_t q = blockIdx.x;
@@ -378,7 +467,11 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
                 ok = false;  // fewer than k candidates although rows were left out
             } else {
                 const float sk = key_to_score_rt(key_skey(kk), metric);
-                const float eps = eps_abs + eps_rel * __builtin_fabsf(t);
+                const float qn = __builtin_sqrtf(__uint_as_float(*max_qn2_bits));
+                const float xn = __builtin_sqrtf(__uint_as_float(*max_xn2_bits));
+                const float eps = eps_mode == 0 ? eps_c * qn * xn
+                                : eps_mode == 1 ? eps_c * __builtin_fabsf(t) + 1e-30f
+                                                : eps_c * (qn + xn) * (qn + xn);
                 ok = metric == M_COSINE ? (sk > t + eps) : (sk < t - eps);
             }
         }
@@ -388,14 +481,14 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
 
 void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
                        const float* d_cand_canon, const float* d_T, int nq, uint32_t kp, uint32_t k,
-                       int metric, uint64_t nrows_total, uint64_t id_offset, float eps_abs,
-                       float eps_rel, uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
+                       int metric, uint64_t id_offset, int eps_mode, float eps_c,
+                       const uint32_t* d_max_qn2_bits, const uint32_t* d_max_xn2_bits,
+                       uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
                        float* d_max_err, hipStream_t s) {
-    (void)nrows_total;
     if (!nq) return;
     size_t lds = sort_lds_bytes(kp);
     if (lds < 2 * kRankSortMax * sizeof(uint64_t)) lds = 2 * kRankSortMax * sizeof(uint64_t);
-    final_topk_kernel<<<nq, kSortThreads, lds, s>>>(d_cand_rows, d_cand_fast, d_cand_canon, d_T, kp, k, metric, id_offset, eps_abs, eps_rel, d_out_ids, d_out_scores, d_status, d_max_err);
+    final_topk_kernel<<<nq, kSortThreads, lds, s>>>(d_cand_rows, d_cand_fast, d_cand_canon, d_T, kp, k, metric, id_offset, eps_mode, eps_c, d_max_qn2_bits, d_max_xn2_bits, d_out_ids, d_out_scores, d_status, d_max_err);
 }
 
 // ------------------------------------------------------------------ exact path output

@@ -252,6 +252,31 @@ static int select_chain(vrod_index* idx, const float* d_scores, uint64_t score_l
     return VROD_OK;
 }
 
+// Stage plan of the MFMA path (DESIGN.md "Kernels").  Stage 0 is a DENSE sample (all scores of
+// the first S rows written out, threshold = exact k'-th best of them); every later stage is a
+// filtered launch over g times more rows than everything before it, followed by a compaction
+// (keep the best k', publish the k'-th score as the next threshold).  Each filtered stage thus
+// expects about g*k' rows per query to beat its threshold: enough that a list cannot come up
+// short, far too few to overflow it or to slow the scan.
+struct StagePlan { uint32_t S, j; std::vector<uint64_t> bounds; };
+static StagePlan plan_stages(uint64_t N, uint32_t kp, uint32_t cap, uint32_t max_sample_rows) {
+    StagePlan p;
+    const uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(8, cap / (3ull * kp)));
+    // sample: N/g^2 rows (two filtered stages follow), at most one round of work-groups
+    // (one 256-row tile per work-group of the dense launch)
+    uint64_t S = std::min<uint64_t>(N / (g * g), max_sample_rows);
+    S = std::max<uint64_t>(S, std::min<uint64_t>(N, std::max<uint64_t>(4ull * kp, kRowTile)));
+    S = std::min<uint64_t>(round_up(S, kRowTile), N);
+    p.S = (uint32_t)S;
+    p.j = (uint32_t)std::min<uint64_t>(kp, S);
+    for (uint64_t b = S * g; b < N; b *= g) {
+        if (N - b < b / 2) break;                    // the tail would be a sliver: fold it in
+        p.bounds.push_back(b / kRowTile * kRowTile);
+    }
+    p.bounds.push_back(N);
+    return p;
+}
+
 static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, uint32_t k,
                       uint64_t* d_out_ids, float* d_out_scores) {
     vrod_search_stats& st = idx->stats;
@@ -270,53 +295,9 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
     // ---- path
     int path = idx->path;
     if (path == VROD_PATH_AUTO) path = nq <= 8 ? VROD_PATH_STREAM : VROD_PATH_MFMA;
-    if (path == VROD_PATH_MFMA && N < 1) path = VROD_PATH_STREAM;
     st.path = path;
 
-    // ---- prepare queries: q_f32 [nq_pad][ld] prepared fp32 (zero padded), q_lp low-precision copy
-    const uint32_t nq_pad = (uint32_t)round_up(nq, path == VROD_PATH_MFMA ? 256 : 8);
-    VROD_TRY(idx->q_f32.ensure((size_t)nq_pad * idx->ld * 4));
-    VROD_TRY(idx->nrm_ws.ensure((size_t)nq * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(idx->q_f32.p, 0, (size_t)nq_pad * idx->ld * 4, s));
-    void* q_lp = nullptr;
-    if (idx->dtype == VROD_DTYPE_BF16) {
-        VROD_TRY(idx->q_lp.ensure((size_t)nq_pad * idx->ld * 2));
-        HIP_TRY(hipMemsetAsync(idx->q_lp.p, 0, (size_t)nq_pad * idx->ld * 2, s));
-        q_lp = idx->q_lp.p;
-    }
-    HIP_TRY(hipMemsetAsync(&idx->flags[1], 0, 8, s));  // max |q|^2 bits, max err bits
-    launch_prepare_rows(d_queries_raw, nq, idx->dim, idx->ld, idx->metric, idx->dtype, idx->nrm_ws.as<double>(),
-                        &idx->flags[0], idx->q_f32.as<float>(), q_lp, s);
-    VROD_TRY(idx->small.ensure((size_t)nq_pad * 4 * 4 + 64));  // qnorm2 | T | thr | status
-    float* d_qn2 = idx->small.as<float>();
-    float* d_T = d_qn2 + nq_pad;
-    float* d_thr = d_T + nq_pad;
-    uint32_t* d_status = (uint32_t*)(d_thr + nq_pad);
-    HIP_TRY(hipMemsetAsync(idx->small.p, 0, (size_t)nq_pad * 4 * 4, s));
-    launch_row_fastnorm(idx->q_f32.p, VROD_DTYPE_F32, nq, idx->ld, d_qn2, &idx->flags[1], s);
-    HIP_TRY(hipGetLastError());
-
-    // host needs: bad flag, max query norm, max row norm (for the certificate bound)
-    uint32_t hflags[3] = {0, 0, 0};
-    uint32_t hmaxx = 0;
-    HIP_TRY(hipMemcpyAsync(hflags, idx->flags, 12, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&hmaxx, idx->max_xn2_bits, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (hflags[0]) {
-        HIP_TRY(hipMemsetAsync(&idx->flags[0], 0, 4, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        return fail(VROD_ERR_INVALID_VALUE, "queries contain NaN or Inf");
-    }
-    float qn2, xn2;
-    memcpy(&qn2, &hflags[1], 4);
-    memcpy(&xn2, &hmaxx, 4);
-    const float qn = std::sqrt(qn2), xn = std::sqrt(xn2);
-    const float u = 5.9604645e-8f;  // 2^-24
-    float eps_abs = 0.f, eps_rel = 0.f;
-
-    VROD_TRY(idx->out_ids.ensure(8));  // keep non-null
-    if (N == 0) {
-        // empty corpus: every slot unfilled
+    if (N == 0) {  // empty corpus: every slot unfilled
         std::vector<uint64_t> hi((size_t)nq * k, UINT64_MAX);
         std::vector<uint32_t> hs((size_t)nq * k, kScoreNoneBits);
         HIP_TRY(hipMemcpyAsync(d_out_ids, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, s));
@@ -324,6 +305,31 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         HIP_TRY(hipStreamSynchronize(s));
         return VROD_OK;
     }
+
+    // ---- prepare queries (one launch): q_f32 [nq_pad][ld] fp32 (zero padded), q_lp bf16 copy,
+    // fast norms, NaN/Inf flag, max |q|^2.  No host round trip: the certificate forms its bound
+    // on the device and the flag is read with the results.
+    const uint32_t nq_pad = (uint32_t)round_up(nq, path == VROD_PATH_MFMA ? 256 : 8);
+    VROD_TRY(idx->q_f32.ensure((size_t)nq_pad * idx->ld * 4));
+    void* q_lp = nullptr;
+    if (idx->dtype == VROD_DTYPE_BF16) {
+        VROD_TRY(idx->q_lp.ensure((size_t)nq_pad * idx->ld * 2));
+        q_lp = idx->q_lp.p;
+    }
+    VROD_TRY(idx->small.ensure((size_t)nq_pad * 4 * 4 + 64));  // qnorm2 | T | thr | status
+    float* d_qn2 = idx->small.as<float>();
+    float* d_T = d_qn2 + nq_pad;
+    float* d_thr = d_T + nq_pad;
+    uint32_t* d_status = (uint32_t*)(d_thr + nq_pad);
+    HIP_TRY(hipMemsetAsync(&idx->flags[1], 0, 8, s));  // max |q|^2 bits, max err bits
+    HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)nq_pad * 4, s));
+    launch_prep_queries(d_queries_raw, nq, nq_pad, idx->dim, idx->ld, idx->metric, idx->dtype, idx->q_f32.as<float>(),
+                        q_lp, d_qn2, &idx->flags[0], &idx->flags[1], s);
+    HIP_TRY(hipGetLastError());
+
+    const float u = 5.9604645e-8f;  // 2^-24
+    int eps_mode = 0;
+    float eps_c = 0.f;
 
     VROD_TRY(idx->cand_rows.ensure((size_t)nq * kp * 4));
     VROD_TRY(idx->cand_fast.ensure((size_t)nq * kp * 4));
@@ -334,8 +340,8 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
 
     if (path == VROD_PATH_STREAM) {
         // -------- fast pass A: HBM-bound scan of <= 8 queries at a time, all N fast scores kept
-        if (idx->metric == VROD_METRIC_COSINE) eps_abs = 4.f * idx->dim * u * qn * xn;
-        else { eps_rel = 4.f * (idx->dim + 2) * u; eps_abs = 1e-30f; }
+        if (idx->metric == VROD_METRIC_COSINE) { eps_mode = 0; eps_c = 4.f * idx->dim * u; }
+        else { eps_mode = 1; eps_c = 4.f * (idx->dim + 2) * u; }
         const uint64_t score_ld = round_up(N, 64);
         VROD_TRY(idx->scores.ensure((size_t)8 * score_ld * 4));
         // radix select, pass 1 fused into the scan: [8][<=4096] bin counters + 8 key counters
@@ -366,63 +372,97 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         }
         HIP_TRY(hipGetLastError());
     } else if (path == VROD_PATH_MFMA) {
-        // -------- fast pass B: batched MFMA scan with a per-query threshold filter, in levels
-        if (idx->metric == VROD_METRIC_COSINE) eps_abs = 4.f * idx->dim * u * qn * xn;
-        else eps_abs = 4.f * (idx->dim + 4) * u * (qn + xn) * (qn + xn);
+        // -------- fast pass B: batched MFMA scan.  (1) dense sample pass over the first S rows,
+        // (2) exact j-th best per query = threshold, (3) ONE filtered launch over all rows,
+        // (4) keep the best k' of every list.
+        if (idx->metric == VROD_METRIC_COSINE) { eps_mode = 0; eps_c = 4.f * idx->dim * u; }
+        else { eps_mode = 2; eps_c = 4.f * (idx->dim + 4) * u; }
         const uint32_t cap = kSelectChunk;
         VROD_TRY(idx->lists.ensure((size_t)nq_pad * cap * 8 + (size_t)nq_pad * 4));
         uint2* d_lists = idx->lists.as<uint2>();
         uint32_t* d_counts = (uint32_t*)((char*)idx->lists.p + (size_t)nq_pad * cap * 8);
         HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nq_pad * 4, s));
-        {   // thr = worst score: nothing filtered at level 0; padding queries never append
-            std::vector<float> w(nq_pad, -worst_score(idx->metric));
-            std::fill(w.begin(), w.begin() + nq, worst_score(idx->metric));
-            HIP_TRY(hipMemcpyAsync(d_thr, w.data(), (size_t)nq_pad * 4, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));
+        {   // thr = worst score (nothing filtered) for real queries; padding queries never append
+            const uint32_t worst_bits = idx->metric == VROD_METRIC_COSINE ? 0xFF800000u : 0x7F800000u;  // -inf / +inf
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_thr, (int)worst_bits, nq, s));
+            if (nq_pad > nq)
+                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(d_thr + nq), (int)(worst_bits ^ 0x80000000u), nq_pad - nq, s));
         }
-        const uint64_t growth = std::max<uint64_t>(4, std::min<uint64_t>(64, cap / (2ull * kp)));
-        uint64_t lo = 0, hi = std::min<uint64_t>(N, std::max<uint64_t>(64, std::min<uint64_t>(2ull * kp, cap / 2)));
         const void* qmat = idx->dtype == VROD_DTYPE_BF16 ? q_lp : idx->q_f32.p;
-        while (lo < N) {
-            // a launch addresses rows relative to its first tile with 24 bits
-            const uint64_t tile_lo = lo / kRowTile * kRowTile;
-            uint64_t end = std::min<uint64_t>(hi, tile_lo + (1ull << 24));
-            MfmaScanArgs a{};
-            a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
-            a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad;
-            a.row_begin = (uint32_t)lo; a.row_end = (uint32_t)end; a.metric = idx->metric;
+        MfmaScanArgs a{};
+        a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
+        a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.metric = idx->metric;
+        std::vector<uint64_t> bounds{N};
+        if (N > cap) {
+            const uint32_t nqb = nq_pad / 256;
+            const StagePlan sp = plan_stages(N, kp, cap, std::max<uint32_t>(1, (uint32_t)idx->num_cus / nqb) * kRowTile);
+            bounds = sp.bounds;
+            const uint32_t dense_ld = (uint32_t)round_up(sp.S, kRowTile);
+            VROD_TRY(idx->scores.ensure((size_t)nq_pad * dense_ld * 4));
+            MfmaScanArgs d = a;
+            d.row_begin = 0; d.row_end = sp.S; d.dense_out = idx->scores.as<float>(); d.dense_ld = dense_ld;
             const size_t e0 = tm.mark();
-            launch_scan_mfma(a, idx->dtype, idx->num_cus, s);
+            launch_scan_mfma(d, idx->dtype, idx->num_cus, s);
             const size_t e1 = tm.mark();
             tm.scan_pairs.push_back({e0, e1});
             st.scan_launches++;
-            st.scan_bytes += (double)(end - tile_lo) * row_bytes_alg;
-            st.scan_flops += 2.0 * nq * (double)(end - lo) * idx->dim;
-            launch_list_compact(d_lists, d_counts, cap, nq, idx->metric, kp, d_thr, d_status, s);
-            lo = end;
-            if (lo >= hi) hi = std::min<uint64_t>(N, hi * growth);
+            st.scan_bytes += (double)dense_ld * row_bytes_alg;
+            st.scan_flops += 2.0 * nq * (double)sp.S * idx->dim;
+            launch_sample_select(idx->scores.as<float>(), dense_ld, sp.S, (int)nq, idx->metric, sp.j, d_thr, s);
         }
-        launch_list_to_candidates(d_lists, d_counts, cap, nq, idx->metric, kp, idx->cand_rows.as<uint32_t>(), idx->cand_fast.as<float>(), d_T, s);
+        uint64_t lo = 0;
+        for (size_t li = 0; li < bounds.size(); ++li) {
+            while (lo < bounds[li]) {
+                // a launch addresses rows relative to its first tile with 24 bits
+                const uint64_t end = std::min<uint64_t>(bounds[li], lo / kRowTile * kRowTile + (1ull << 24));
+                a.row_begin = (uint32_t)lo; a.row_end = (uint32_t)end;
+                const size_t e0 = tm.mark();
+                launch_scan_mfma(a, idx->dtype, idx->num_cus, s);
+                const size_t e1 = tm.mark();
+                tm.scan_pairs.push_back({e0, e1});
+                st.scan_launches++;
+                st.scan_bytes += (double)(end - lo / kRowTile * kRowTile) * row_bytes_alg;
+                st.scan_flops += 2.0 * nq * (double)(end - lo) * idx->dim;
+                lo = end;
+            }
+            launch_list_compact(d_lists, d_counts, cap, (int)nq, idx->metric, kp, d_thr, d_status, s);
+        }
+        launch_list_to_candidates(d_lists, d_counts, cap, (int)nq, idx->metric, kp, idx->cand_rows.as<uint32_t>(), idx->cand_fast.as<float>(), d_T, s);
         HIP_TRY(hipMemcpyAsync(d_T, d_thr, (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipGetLastError());
     }
 
+    uint32_t hflags[3] = {0, 0, 0};
+    uint32_t hmaxx = 0;
     if (path == VROD_PATH_EXACT) {
         std::fill(hstatus.begin(), hstatus.end(), 1u);
+        HIP_TRY(hipMemcpyAsync(hflags, idx->flags, 12, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
     } else {
         // -------- canonical re-score + final ordering + certificate
         launch_rescore_candidates(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, idx->q_f32.as<float>(), (int)nq,
                                   idx->cand_rows.as<uint32_t>(), kp, idx->cand_canon.as<float>(), s);
         launch_final_topk(idx->cand_rows.as<uint32_t>(), idx->cand_fast.as<float>(), idx->cand_canon.as<float>(), d_T, (int)nq, kp, k,
-                          idx->metric, N, idx->id_offset, eps_abs, eps_rel, d_out_ids, d_out_scores, d_status, (float*)&idx->flags[2], s);
+                          idx->metric, idx->id_offset, eps_mode, eps_c, &idx->flags[1], idx->max_xn2_bits, d_out_ids, d_out_scores,
+                          d_status, (float*)&idx->flags[2], s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(hstatus.data(), d_status, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&hflags[2], &idx->flags[2], 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(hflags, idx->flags, 12, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&hmaxx, idx->max_xn2_bits, 4, hipMemcpyDeviceToHost, s));
         tm.t1 = tm.mark();
         HIP_TRY(hipStreamSynchronize(s));
         memcpy(&st.max_fast_err, &hflags[2], 4);
+        float qn2, xn2;
+        memcpy(&qn2, &hflags[1], 4);
+        memcpy(&xn2, &hmaxx, 4);
+        const float qn = std::sqrt(qn2), xn = std::sqrt(xn2);
+        st.eps_bound = eps_mode == 0 ? eps_c * qn * xn : eps_mode == 1 ? eps_c * 4.0f : eps_c * (qn + xn) * (qn + xn);
     }
-    st.eps_bound = eps_abs + eps_rel * 4.0f;
+    if (hflags[0]) {  // NaN/Inf in the queries: whatever was computed is void
+        HIP_TRY(hipMemsetAsync(&idx->flags[0], 0, 4, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return fail(VROD_ERR_INVALID_VALUE, "queries contain NaN or Inf");
+    }
 
     // -------- exact path for uncertified queries: canonical score of every row, exact select
     for (uint32_t qi = 0; qi < nq; ++qi) {

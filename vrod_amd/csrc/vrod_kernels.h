@@ -11,6 +11,11 @@ void launch_synth_rows(uint64_t seed, uint64_t first_row, uint64_t n, uint32_t d
 void launch_prepare_rows(const float* d_in, uint64_t n, uint32_t dim, uint32_t ld, int metric,
                          int dtype, double* d_nrm_ws, uint32_t* d_bad_flag, float* d_out_f32,
                          void* d_out_bf16, hipStream_t s);
+// Queries: normalise (COSINE) / round (BF16) / zero-pad to [nq_pad][ld] in ONE launch; also the
+// fast squared norms qn2[nq_pad], the NaN/Inf flag and the max squared norm (float bits).
+void launch_prep_queries(const float* d_in, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t ld, int metric,
+                         int dtype, float* d_out_f32, void* d_out_bf16, float* d_qn2, uint32_t* d_bad_flag,
+                         uint32_t* d_max_bits, hipStream_t s);
 void launch_row_fastnorm(const void* d_rows, int dtype, uint64_t n, uint32_t ld, float* d_xn2,
                          uint32_t* d_max_bits, hipStream_t s);
 void launch_rows_get(const void* d_rows, int dtype, uint64_t n, uint32_t dim, uint32_t ld,
@@ -53,8 +58,13 @@ void launch_keys_to_candidates(const uint64_t* d_keys, uint64_t key_ld, uint64_t
 // MFMA path: per-query candidate lists {fast score bits, row} appended by the scan kernel.
 // Sort each list, keep the best `keep`, write thr[q] = keep-th fast score (worst if short),
 // flag overflow (count > cap) in d_status[q] bit 1.
+// A list shorter than `keep` leaves thr[q] unchanged (rows were still left out at that threshold).
 void launch_list_compact(uint2* d_lists, uint32_t* d_counts, uint32_t cap, int nq, int metric,
                          uint32_t keep, float* d_thr, uint32_t* d_status, hipStream_t s);
+// Sample pass: thr[q] = the j-th best of the n_sample fast scores scores[q][0..n_sample)
+// (exact, 3-pass radix select on the order-preserving key).  One block per query.
+void launch_sample_select(const float* d_scores, uint64_t score_ld, uint32_t n_sample, int nq,
+                          int metric, uint32_t j, float* d_thr, hipStream_t s);
 // lists (after compaction) -> candidates as above.
 void launch_list_to_candidates(const uint2* d_lists, const uint32_t* d_counts, uint32_t cap, int nq,
                                int metric, uint32_t kp, uint32_t* d_cand_rows, float* d_cand_fast,
@@ -62,11 +72,14 @@ void launch_list_to_candidates(const uint2* d_lists, const uint32_t* d_counts, u
 
 // Final: canonical scores of the kp candidates -> sorted top-k (ids u64 = row + id_offset),
 // certificate per query in d_status bit 0 (1 = NOT certified).
-// eps_abs / eps_rel: |fast - canonical| <= eps_abs + eps_rel * |canonical-or-fast|.
+// The certificate's bound on |fast - canonical| is formed on the device from the max squared
+// norms (float bits) of the queries and of the corpus:  eps_mode 0: c * |q| * |x|  (dot paths),
+// 1: c relative to T (direct L2),  2: c * (|q| + |x|)^2 (L2 through the norm expansion).
 void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
                        const float* d_cand_canon, const float* d_T, int nq, uint32_t kp, uint32_t k,
-                       int metric, uint64_t nrows_total, uint64_t id_offset, float eps_abs,
-                       float eps_rel, uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
+                       int metric, uint64_t id_offset, int eps_mode, float eps_c,
+                       const uint32_t* d_max_qn2_bits, const uint32_t* d_max_xn2_bits,
+                       uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
                        float* d_max_err, hipStream_t s);
 
 // Exact path: canonical scores (implicit ids) -> exact top-k, via the same select chain with
@@ -104,6 +117,8 @@ struct MfmaScanArgs {
     uint32_t row_begin;     // appends are limited to rows [row_begin, row_end); the launch
     uint32_t row_end;       // starts at the 256-row tile containing row_begin
     int metric;
+    float* dense_out;       // non-null: sample pass, write every fast score [nq_pad][dense_ld]
+    uint32_t dense_ld;      // (column = row - row_begin; multiple of 256)
 };
 void launch_scan_mfma(const MfmaScanArgs& a, int dtype, int num_cus, hipStream_t s);
 
