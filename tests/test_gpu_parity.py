@@ -245,3 +245,14 @@ def test_synthetic_add_equals_host_add(va, oracle):
         a.add_synthetic(1, 1000, 5000)
         b.add(raw)
         assert np.array_equal(bits(a.get_rows(0, 5000)), bits(b.get_rows(0, 5000)))
+
+
+def test_mfma_small_corpus_everything_appended(va, oracle):
+    """N <= list capacity: no sample pass, thresholds stay 'worst', every (row, query) pair goes
+    through the LDS log (overflowing it: direct global appends) and the lists hold all N rows."""
+    rng = np.random.default_rng(33)
+    raw = rng.standard_normal((8000, 64)).astype(np.float32)
+    rq = rng.standard_normal((300, 64)).astype(np.float32)
+    for dtype in ("bf16", "f32"):
+        st = run_case(va, oracle, raw, rq, 10, dtype, "cosine", 2)
+        assert st["scan_launches"] == 1 and st["fallback_queries"] == 0

@@ -85,6 +85,8 @@ struct MfmaKernelArgs {
     uint32_t slots;         // work-groups per XCD label (gridDim.x / 8)
     float* dense_out;       // DENSE launches: fast scores [nq_pad][dense_ld], column = row - row_lo
     uint32_t dense_ld;
+    uint32_t* pace;         // [nstrips] arrival counters of the sibling work-groups (zeroed per launch)
+    uint32_t pace_every;    // re-align the siblings of a strip every this many tiles (0 = never)
 };
 
 template <int METRIC>
@@ -116,9 +118,11 @@ __device__ __forceinline__ bool wg_assignment(const MfmaKernelArgs& a, uint32_t&
 }
 
 // Drain the LDS log into the per-query lists.  Called by ALL threads at the same program
-// point with no append in flight.  Uses two block barriers.
+// point; the leading barrier makes sure every wave's appends (a wave group may still be in
+// its tile filter) are in the log.  Uses three block barriers.
 __device__ __forceinline__ void flush_log(const MfmaKernelArgs& a, uint2* log, uint32_t* log_cnt, uint32_t qb,
                                           uint32_t rel_base, int tid) {
+    __syncthreads();
     const uint32_t n = log_cnt[0] < (uint32_t)kLogCap ? log_cnt[0] : (uint32_t)kLogCap;
     for (uint32_t i = tid; i < n; i += 512) {
         const uint2 e = log[i];
@@ -510,6 +514,22 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                 \
     VROD_BARRIER();
 
+            // ---------------- pacing: the nqb work-groups that walk the same strip (one per query
+            // block, same XCD) must stay within about one tile of each other or the corpus tile
+            // they share falls out of the XCD's L2 and is fetched from HBM once per work-group.
+            // Nothing but speed depends on it: relaxed agent-scope counter, bounded spin.
+            if (a.pace_every && kt == 0 && it > 0 && tid == 0) {
+                const uint32_t tix = it / KT;
+                if (tix % a.pace_every == 0) {
+                    uint32_t* ctr = a.pace + strip;
+                    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t want = a.nqb * (tix / a.pace_every);
+                    for (uint32_t spin = 0; spin < 200000u; ++spin) {
+                        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+            }
             // ---------------- phase 0: quadrant (0,0), stages A_m0 of the next K-tile
             VROD_LOAD_A(0)
             VROD_LOAD_B(0)
@@ -538,6 +558,10 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
             VROD_STAGE_L(A, 8)
             VROD_PHASE_SYNC()
             VROD_COMPUTE(1, 0, A, 8)
+            VROD_BARRIER();
+            // A finished corpus tile is filtered AFTER this barrier, i.e. in this group's load slot,
+            // so the other group's MFMA segment runs meanwhile (inside the compute segment it would
+            // stall both groups).  The accumulators are not touched again before the next compute.
             if (kt == KT - 1) {
                 const uint32_t tile = t0 + it / KT;
                 if constexpr (DENSE)
@@ -545,7 +569,6 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
                 else
                     filter_tile<METRIC>(a, acc, thr, qn2, tile * kBM + wr * 128 + fg * 4, wc * 64 + fr, qb, rel_base, log, log_cnt);
             }
-            VROD_BARRIER();
 
             if (flush_now) {
                 // re-align the groups (group 0 waits one barrier), flush, stagger again
@@ -593,11 +616,16 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     a.row_end = h.row_end;
     a.dense_out = h.dense_out;
     a.dense_ld = h.dense_ld;
+    static const int pace_env = [] { const char* e = getenv("VROD_MFMA_PACE"); return e ? atoi(e) : 8; }();
+    a.pace = h.pace;
     int grid = num_cus / 8 * 8;
     if (grid < 8) grid = 8;
     a.slots = grid / 8;
     a.strips_per_xcd = a.nqb <= a.slots ? a.slots / a.nqb : 1;
     a.nstrips = 8 * a.strips_per_xcd;
+    // pacing only where several work-groups share a strip (one per query block) and one pass each
+    a.pace_every = (h.pace && a.nqb > 1 && a.nqb <= a.slots && pace_env > 0) ? (uint32_t)pace_env : 0u;
+    if (a.pace_every) (void)hipMemsetAsync(a.pace, 0, a.nstrips * sizeof(uint32_t), s);
     static const bool simple = [] { const char* e = getenv("VROD_MFMA_SIMPLE"); return e && e[0] == '1'; }();
 #define VROD_MFMA(KERNEL, TT, MM)                                                                           \
     do {                                                                                                    \

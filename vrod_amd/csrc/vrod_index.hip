@@ -392,6 +392,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
         a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.metric = idx->metric;
+        a.pace = idx->flags + 64;  // the tail of the 2 KB flags block: room for 448 strips
         std::vector<uint64_t> bounds{N};
         if (N > cap) {
             const uint32_t nqb = nq_pad / 256;
@@ -529,8 +530,8 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
     do {
         if (hipSetDevice(dev) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipSetDevice failed"); break; }
         if (hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipStreamCreate failed"); break; }
-        if (hipMalloc((void**)&idx->flags, 64) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
-        if (hipMemset(idx->flags, 0, 64) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
+        if (hipMalloc((void**)&idx->flags, 2048) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
+        if (hipMemset(idx->flags, 0, 2048) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
         idx->max_xn2_bits = idx->flags + 8;
     } while (0);
     if (rc != VROD_OK) { vrod_index_destroy(idx); return rc; }

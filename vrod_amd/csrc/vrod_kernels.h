@@ -117,6 +117,7 @@ struct MfmaScanArgs {
     uint32_t row_begin;     // appends are limited to rows [row_begin, row_end); the launch
     uint32_t row_end;       // starts at the 256-row tile containing row_begin
     int metric;
+    uint32_t* pace;         // >= 64 words of scratch for the sibling pacing counters (may be null)
     float* dense_out;       // non-null: sample pass, write every fast score [nq_pad][dense_ld]
     uint32_t dense_ld;      // (column = row - row_begin; multiple of 256)
 };
