@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvrod_hip.so")
+# VROD_HIP_LIB: load another build of the same library (A/B timing of two builds in one gpurun call)
+LIB_PATH = os.environ.get("VROD_HIP_LIB") or os.path.join(_HERE, "libvrod_hip.so")
 
 # every symbol include/vrod.h declares (tests check the library exports exactly these)
 SYMBOLS = [
@@ -47,6 +48,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.  If torch is
+    # going to be used in this process (tests, bench) it must load first so that this library
+    # binds to the same runtime; loaded the other way round the second runtime sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

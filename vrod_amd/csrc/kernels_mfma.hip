@@ -454,6 +454,7 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
         // fragment registers: A half (4 m-tiles x 2 k-halves), B half (2 n-tiles x 2 k-halves)
         typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type frag_t;
         frag_t af[4][2], bf[2][2];
+        frag_t bf0[2][2];   // the nh = 0 query fragments stay live from phase 0 to phase 3 (no LDS re-read)
 
         for (uint32_t it = 0; it < total_it; ++it) {
             const uint32_t buf = it & 1;
@@ -476,10 +477,10 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
         af[mm][0] = *reinterpret_cast<const frag_t*>(l + a_frag0 + ((MH) * 4 + mm) * 2048 + c_off0);    \
         af[mm][1] = *reinterpret_cast<const frag_t*>(l + a_frag0 + ((MH) * 4 + mm) * 2048 + c_off1);    \
     }
-#define VROD_LOAD_B(NH)                                                                                   \
+#define VROD_LOAD_B(BF, NH)                                                                               \
     _Pragma("unroll") for (int nn = 0; nn < 2; ++nn) {                                                   \
-        bf[nn][0] = *reinterpret_cast<const frag_t*>(l + b_frag0 + ((NH) * 2 + nn) * 2048 + c_off0);    \
-        bf[nn][1] = *reinterpret_cast<const frag_t*>(l + b_frag0 + ((NH) * 2 + nn) * 2048 + c_off1);    \
+        BF[nn][0] = *reinterpret_cast<const frag_t*>(l + b_frag0 + ((NH) * 2 + nn) * 2048 + c_off0);    \
+        BF[nn][1] = *reinterpret_cast<const frag_t*>(l + b_frag0 + ((NH) * 2 + nn) * 2048 + c_off1);    \
     }
 #define VROD_STAGE_A1(OFF, I)                                                                             \
     VROD_GLDS16(a_src + (uint64_t)(pa[I] + (OFF)) * 8 * a.ld_bytes, lnext + (pa[I] + (OFF)) * 1024);
@@ -489,24 +490,24 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
 #define VROD_STAGE_L(KIND, OFF)                                                                           \
     if constexpr (GP <= 1) { VROD_STAGE_##KIND##1(OFF, 0) }                                               \
     if constexpr (GP == 0) { VROD_STAGE_##KIND##1(OFF, 1) }
-#define VROD_MFMA_ONE(MH, NH, KK, MM, NN)                                                                 \
+#define VROD_MFMA_ONE(BF, MH, NH, KK, MM, NN)                                                             \
     if constexpr (sizeof(T) == 2) {                                                                       \
         acc[(MH) * 4 + MM][(NH) * 2 + NN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
-            af[MM][KK], bf[NN][KK], acc[(MH) * 4 + MM][(NH) * 2 + NN], 0, 0, 0);                          \
+            af[MM][KK], BF[NN][KK], acc[(MH) * 4 + MM][(NH) * 2 + NN], 0, 0, 0);                          \
     } else {                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
             acc[(MH) * 4 + MM][(NH) * 2 + NN] = __builtin_amdgcn_mfma_f32_16x16x4f32(                     \
-                af[MM][KK][i], bf[NN][KK][i], acc[(MH) * 4 + MM][(NH) * 2 + NN], 0, 0, 0);                \
+                af[MM][KK][i], BF[NN][KK][i], acc[(MH) * 4 + MM][(NH) * 2 + NN], 0, 0, 0);                \
     }
-#define VROD_MFMA_ROW(MH, NH, KK, MM) VROD_MFMA_ONE(MH, NH, KK, MM, 0) VROD_MFMA_ONE(MH, NH, KK, MM, 1)
+#define VROD_MFMA_ROW(BF, MH, NH, KK, MM) VROD_MFMA_ONE(BF, MH, NH, KK, MM, 0) VROD_MFMA_ONE(BF, MH, NH, KK, MM, 1)
 // 16 MFMAs; DMA pieces dropped in after the 4th and the 10th when GP says so
-#define VROD_COMPUTE(MH, NH, KIND, OFF)                                                                   \
+#define VROD_COMPUTE(BF, MH, NH, KIND, OFF)                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                        \
-    VROD_MFMA_ROW(MH, NH, 0, 0) VROD_MFMA_ROW(MH, NH, 0, 1)                                               \
+    VROD_MFMA_ROW(BF, MH, NH, 0, 0) VROD_MFMA_ROW(BF, MH, NH, 0, 1)                                       \
     if constexpr (GP == 2) { VROD_STAGE_##KIND##1(OFF, 0) }                                               \
-    VROD_MFMA_ROW(MH, NH, 0, 2) VROD_MFMA_ROW(MH, NH, 0, 3) VROD_MFMA_ROW(MH, NH, 1, 0)                   \
+    VROD_MFMA_ROW(BF, MH, NH, 0, 2) VROD_MFMA_ROW(BF, MH, NH, 0, 3) VROD_MFMA_ROW(BF, MH, NH, 1, 0)       \
     if constexpr (GP >= 1) { VROD_STAGE_##KIND##1(OFF, 1) }                                               \
-    VROD_MFMA_ROW(MH, NH, 1, 1) VROD_MFMA_ROW(MH, NH, 1, 2) VROD_MFMA_ROW(MH, NH, 1, 3)                   \
+    VROD_MFMA_ROW(BF, MH, NH, 1, 1) VROD_MFMA_ROW(BF, MH, NH, 1, 2) VROD_MFMA_ROW(BF, MH, NH, 1, 3)       \
     __builtin_amdgcn_s_setprio(0);
 #define VROD_PHASE_SYNC()                                                                                 \
     if constexpr (GP == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                               \
@@ -532,32 +533,31 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
             }
             // ---------------- phase 0: quadrant (0,0), stages A_m0 of the next K-tile
             VROD_LOAD_A(0)
-            VROD_LOAD_B(0)
+            VROD_LOAD_B(bf0, 0)
             VROD_STAGE_L(A, 0)
             VROD_PHASE_SYNC()
-            VROD_COMPUTE(0, 0, A, 0)
+            VROD_COMPUTE(bf0, 0, 0, A, 0)
             VROD_BARRIER();
 
             // ---------------- phase 1: quadrant (0,1), stages B_n0
             if (kt == 0 && it > 0) flush_now = log_cnt[3] != 0u;  // previous tile's appends are all done
-            VROD_LOAD_B(1)
+            VROD_LOAD_B(bf, 1)
             VROD_STAGE_L(B, 0)
             VROD_PHASE_SYNC()
-            VROD_COMPUTE(0, 1, B, 0)
+            VROD_COMPUTE(bf, 0, 1, B, 0)
             VROD_BARRIER();
 
             // ---------------- phase 2: quadrant (1,1), stages B_n1
             VROD_LOAD_A(1)
             VROD_STAGE_L(B, 4)
             VROD_PHASE_SYNC()
-            VROD_COMPUTE(1, 1, B, 4)
+            VROD_COMPUTE(bf, 1, 1, B, 4)
             VROD_BARRIER();
 
-            // ---------------- phase 3: quadrant (1,0), stages A_m1
-            VROD_LOAD_B(0)
+            // ---------------- phase 3: quadrant (1,0), stages A_m1 (B_n0 fragments still in registers)
             VROD_STAGE_L(A, 8)
             VROD_PHASE_SYNC()
-            VROD_COMPUTE(1, 0, A, 8)
+            VROD_COMPUTE(bf0, 1, 0, A, 8)
             VROD_BARRIER();
             // A finished corpus tile is filtered AFTER this barrier, i.e. in this group's load slot,
             // so the other group's MFMA segment runs meanwhile (inside the compute segment it would
