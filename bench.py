@@ -61,13 +61,12 @@ def parse():
 
 def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev):
     """Run `steps` batches; returns accumulated library stats of this rank."""
-    from vrod_amd.shard import all_gather_topk
+    from vrod_amd.shard import all_gather_packed, alloc_packed
     nq, k = wl["nq"], wl["k"]
-    oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    osc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    # this rank's results live in one packed block (ids | scores): the exchange is ONE all-gather
+    packed, oi, osc = alloc_packed(nq, k, dev)
     if world > 1:
-        gi = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
-        gs = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
+        gathered = torch.empty(world * packed.numel(), dtype=torch.uint8, device=dev)
         mi = torch.empty((nq, k), dtype=torch.int64, device=dev)
         ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
     acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, total_ms=0.0, max_err=0.0, eps=0.0)
@@ -76,8 +75,8 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev):
         st = ix.last_stats()
         if world > 1:
             # per-shard top-k -> every rank (RCCL all-gather over xGMI), then the exact merge
-            all_gather_topk(dist, oi, osc, gi, gs)
-            va.merge_topk_device(dev.index, wl["metric"], gi, gs, mi, ms)
+            all_gather_packed(dist, packed, gathered)
+            va.merge_topk_packed_device(dev.index, wl["metric"], gathered, world, nq, k, mi, ms)
         acc["scan_ms"] += st["scan_ms"]
         acc["scan_flops"] += st["scan_flops"]
         acc["scan_bytes"] += st["scan_bytes"]

@@ -116,6 +116,12 @@ int vrod_merge_topk_device(int device, int metric, const uint64_t *d_ids,
                            uint32_t k, uint64_t *d_out_ids, float *d_out_scores,
                            void *stream);
 
+/* Same merge over ONE packed buffer: per list, nq*k ids (u64) immediately followed by nq*k
+ * scores (f32) -- the layout that lets the exchange be a single all-gather. nq*k must be even. */
+int vrod_merge_topk_packed_device(int device, int metric, const void *d_packed, uint32_t n_lists,
+                                  uint32_t nq, uint32_t k, uint64_t *d_out_ids,
+                                  float *d_out_scores, void *stream);
+
 /* --- knobs & introspection -------------------------------------------------- */
 int vrod_index_set_path(vrod_index *idx, int path);      /* VROD_PATH_* (default AUTO) */
 int vrod_index_set_profiling(vrod_index *idx, int on);   /* HIP-event timing of kernels */

@@ -26,7 +26,7 @@ def _worker(rank, world, port, n_total, dim, nq, k, metric, q):
     import torch
     import torch.distributed as dist
     from oracle import oracle as O
-    from vrod_amd.shard import all_gather_topk, shard_range
+    from vrod_amd.shard import all_gather_packed, all_gather_topk, alloc_packed, shard_range, unpack_gathered
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(n_total, rank, world)
     raw = O.synth_rows(1, lo, hi - lo, dim)           # this rank's rows of the shared stream
@@ -34,6 +34,12 @@ def _worker(rank, world, port, n_total, dim, nq, k, metric, q):
     ids, sc = O.search(raw, rq, k, 0, metric, id_offset=lo)
     gi, gs = all_gather_topk(dist, torch.from_numpy(ids.view(np.int64)), torch.from_numpy(sc))
     mi, ms = O.merge_topk(gi.numpy().view(np.uint64), gs.numpy(), metric)
+    # the packed single-collective form bench.py uses (ids | scores in one byte block per rank)
+    packed, pi, ps = alloc_packed(nq, k, "cpu")
+    pi.copy_(torch.from_numpy(ids.view(np.int64)))
+    ps.copy_(torch.from_numpy(sc))
+    ui, us = unpack_gathered(all_gather_packed(dist, packed), world, nq, k)
+    assert np.array_equal(ui, gi.numpy().view(np.uint64)) and np.array_equal(us.view(np.uint32), gs.numpy().view(np.uint32))
     if rank == 0:
         q.put((mi, ms))
     dist.barrier()

@@ -256,3 +256,28 @@ def test_mfma_small_corpus_everything_appended(va, oracle):
     for dtype in ("bf16", "f32"):
         st = run_case(va, oracle, raw, rq, 10, dtype, "cosine", 2)
         assert st["scan_launches"] == 1 and st["fallback_queries"] == 0
+
+
+def test_merge_topk_packed_device(va, oracle):
+    """The single-all-gather layout: per shard nq*k ids (u64) then nq*k scores (f32) in one block."""
+    import torch
+    from vrod_amd.shard import alloc_packed
+    rng = np.random.default_rng(13)
+    raw = rng.standard_normal((3000, 32)).astype(np.float32)
+    rq = rng.standard_normal((6, 32)).astype(np.float32)
+    k, G = 10, 3
+    blocks = []
+    for g in range(G):
+        lo, hi = g * 1000, (g + 1) * 1000
+        with va.Index(32, "f32", "l2") as ix:
+            ix.add(raw[lo:hi])
+            ix.set_id_offset(lo)
+            packed, pi, ps = alloc_packed(6, k, torch.device("cuda", 0))
+            ix.search_device(torch.from_numpy(rq).cuda(), k, pi, ps)
+            blocks.append(packed)
+    gathered = torch.cat(blocks)
+    mi = torch.empty((6, k), dtype=torch.int64, device="cuda")
+    ms = torch.empty((6, k), dtype=torch.float32, device="cuda")
+    va.merge_topk_packed_device(0, "l2", gathered, G, 6, k, mi, ms)
+    oi, osc = oracle.search(raw, rq, k, 0, 1)
+    assert_same(mi.cpu().numpy().view(np.uint64), ms.cpu().numpy(), oi, osc, "packed merge")

@@ -7,6 +7,6 @@ the thin harness that loads it.  No CPU or PyTorch fallback exists.
 from ._lib import LIB_PATH, SYMBOLS, SearchStats, VrodError, load  # noqa: F401
 from .index import (DTYPE_BF16, DTYPE_F32, ID_NONE, MAX_K, METRIC_COSINE, METRIC_L2,  # noqa: F401
                     PATH_AUTO, PATH_EXACT, PATH_MFMA, PATH_STREAM, Index, merge_topk_device,
-                    synth_rows_device)
+                    merge_topk_packed_device, synth_rows_device)
 
-__all__ = ["Index", "VrodError", "merge_topk_device", "synth_rows_device", "load", "LIB_PATH", "SYMBOLS"]
+__all__ = ["Index", "VrodError", "merge_topk_device", "merge_topk_packed_device", "synth_rows_device", "load", "LIB_PATH", "SYMBOLS"]

@@ -95,21 +95,33 @@ __global__ __launch_bounds__(256) void row_write_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ fast squared norms of stored rows
-// fp32, one wave per row (used by the L2 fast pass and for the certificate's bound).
+// fp32, one wave per row, 16-B loads (rows are whole 128-B lines: ld*sizeof(T) % 128 == 0).
+// Used by the L2 fast pass and for the certificate's bound.
 template <typename T>
 __global__ __launch_bounds__(256) void row_fastnorm_kernel(const T* __restrict__ rows, uint64_t n,
                                                            uint32_t ld, float* __restrict__ xn2,
                                                            uint32_t* __restrict__ max_bits) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t units = ld * (uint32_t)sizeof(T) / 16;
     for (uint64_t r = wave; r < n; r += nwaves) {
-        const T* x = rows + r * (uint64_t)ld;
+        const u32x4* x = reinterpret_cast<const u32x4*>(rows + r * (uint64_t)ld);
         float s = 0.0f;
-        for (uint32_t j = lane; j < ld; j += 64) {
-            float v;
-            if constexpr (sizeof(T) == 2) v = bf16_to_f32(x[j]); else v = x[j];
-            s = __builtin_fmaf(v, v, s);
+        for (uint32_t j = lane; j < units; j += 64) {
+            const u32x4 v = x[j];
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xFFFF0000u);
+                    s = __builtin_fmaf(lo, lo, s);
+                    s = __builtin_fmaf(hi, hi, s);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float f = __uint_as_float(v[e]); s = __builtin_fmaf(f, f, s); }
+            }
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) {

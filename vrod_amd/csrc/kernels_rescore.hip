@@ -83,8 +83,10 @@ __global__ __launch_bounds__(64) void rescore_kernel(const T* __restrict__ corpu
     const int sub = lane / LPC, part = lane % LPC;
 
     float acc = 0.0f;
-    for (uint32_t j0 = 0; j0 < dim; j0 += 64) {
-        u32x4 v[NI];
+    // the row gather of chunk c+1 is issued before the chain of chunk c runs (the chain is
+    // sequential and latency-bound; the loads must not be)
+    u32x4 v[NI];
+    auto fetch = [&](uint32_t j0) {
         const uint32_t e0 = j0 + part * EPU;  // first element this lane fetches
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
@@ -94,6 +96,9 @@ __global__ __launch_bounds__(64) void rescore_kernel(const T* __restrict__ corpu
                 if (e0 < ld) v[it] = *reinterpret_cast<const u32x4*>(corpus + (uint64_t)row * ld + e0);
             }
         }
+    };
+    fetch(0);
+    for (uint32_t j0 = 0; j0 < dim; j0 += 64) {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             float* t = tile + (it * RPI + sub) * kTileStride + part * EPU;
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(const T* __restrict__ corpu
                 *reinterpret_cast<u32x4*>(t + 4) = u32x4{v[it].z << 16, v[it].z & 0xFFFF0000u, v[it].w << 16, v[it].w & 0xFFFF0000u};
             }
         }
+        if (j0 + 64 < dim) fetch(j0 + 64);
         // the tile (and q_lds on the first pass) is wave-private: in-order LDS + a compiler fence
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

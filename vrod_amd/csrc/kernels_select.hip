@@ -259,7 +259,8 @@ void launch_hist_compact(const float* d_scores, uint64_t score_ld, uint64_t n, i
 constexpr uint32_t kCompactThreads = 256;
 __global__ __launch_bounds__(kCompactThreads) void list_compact_kernel(
     uint2* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t cap, int metric,
-    uint32_t keep, uint32_t wsize, float* __restrict__ thr, uint32_t* __restrict__ status) {
+    uint32_t keep, uint32_t wsize, float* __restrict__ thr, uint32_t* __restrict__ status,
+    uint32_t* __restrict__ cand_rows, float* __restrict__ cand_fast, float* __restrict__ T) {
     extern __shared__ __attribute__((aligned(16))) uint64_t win[];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t c = counts[q];
@@ -288,37 +289,29 @@ __global__ __launch_bounds__(kCompactThreads) void list_compact_kernel(
         const uint64_t key = win[i];
         l[i] = make_uint2(__float_as_uint(key_to_score_rt(key_skey(key), metric)), key_row(key));
     }
+    // last compaction of a search: also emit the candidate arrays (rows, fast scores, T)
+    if (cand_rows) {
+        for (uint32_t i = tid; i < keep; i += kCompactThreads) {
+            const uint64_t key = i < have ? win[i] : 0ull;
+            cand_rows[(uint64_t)q * keep + i] = i < have ? key_row(key) : 0xFFFFFFFFu;
+            cand_fast[(uint64_t)q * keep + i] = i < have ? key_to_score_rt(key_skey(key), metric) : __uint_as_float(kScoreNoneBits);
+        }
+    }
     if (tid == 0) {
         counts[q] = have;
-        if (n >= keep && have >= keep) thr[q] = key_to_score_rt(key_skey(win[keep - 1]), metric);  // else: unchanged
+        float t = thr[q];
+        if (n >= keep && have >= keep) { t = key_to_score_rt(key_skey(win[keep - 1]), metric); thr[q] = t; }  // else: unchanged
+        if (T) T[q] = t;
         if (c > cap) atomicOr(&status[q], 2u);
     }
 }
 
 void launch_list_compact(uint2* d_lists, uint32_t* d_counts, uint32_t cap, int nq, int metric,
-                         uint32_t keep, float* d_thr, uint32_t* d_status, hipStream_t s) {
+                         uint32_t keep, float* d_thr, uint32_t* d_status, uint32_t* d_cand_rows,
+                         float* d_cand_fast, float* d_T, hipStream_t s) {
     const uint32_t wsize = keep <= 1024 ? 2048u : kSelectChunk;
-    list_compact_kernel<<<nq, kCompactThreads, (size_t)wsize * 8, s>>>(d_lists, d_counts, cap, metric, keep, wsize, d_thr, d_status);
-}
-
-__global__ __launch_bounds__(256) void list_to_candidates_kernel(
-    const uint2* __restrict__ lists, const uint32_t* __restrict__ counts, uint32_t cap,
-    uint32_t kp, uint32_t* __restrict__ cand_rows, float* __restrict__ cand_fast) {
-    const uint32_t q = blockIdx.x;
-    const uint32_t n = counts[q] < kp ? counts[q] : kp;
-    for (uint32_t i = threadIdx.x; i < kp; i += blockDim.x) {
-        uint2 e = make_uint2(kScoreNoneBits, 0xFFFFFFFFu);
-        if (i < n) e = lists[(uint64_t)q * cap + i];
-        cand_rows[(uint64_t)q * kp + i] = e.y;
-        cand_fast[(uint64_t)q * kp + i] = __uint_as_float(e.x);
-    }
-}
-
-void launch_list_to_candidates(const uint2* d_lists, const uint32_t* d_counts, uint32_t cap, int nq,
-                               int metric, uint32_t kp, uint32_t* d_cand_rows, float* d_cand_fast,
-                               float* d_T, hipStream_t s) {
-    (void)metric; (void)d_T;  // T[q] is the thr[] written by the last list_compact(keep = kp)
-    list_to_candidates_kernel<<<nq, 256, 0, s>>>(d_lists, d_counts, cap, kp, d_cand_rows, d_cand_fast);
+    list_compact_kernel<<<nq, kCompactThreads, (size_t)wsize * 8, s>>>(d_lists, d_counts, cap, metric, keep, wsize, d_thr, d_status,
+                                                                     d_cand_rows, d_cand_fast, d_T);
 }
 
 // ------------------------------------------------------------------ sample pass: exact j-th best
@@ -524,6 +517,7 @@ __device__ __forceinline__ bool ranks_before(uint32_t ka, uint64_t ia, uint32_t 
 
 __global__ __launch_bounds__(256) void merge_topk_kernel(int metric, const uint64_t* __restrict__ ids,
                                                          const float* __restrict__ scores,
+                                                         uint64_t list_stride_ids, uint64_t list_stride_scores,
                                                          uint32_t n_lists, uint32_t nq, uint32_t k,
                                                          uint64_t* __restrict__ out_ids,
                                                          float* __restrict__ out_scores) {
@@ -536,21 +530,23 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(int metric, const uint6
     const uint32_t total = n_lists * k;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         const uint32_t li = e / k, pi = e - li * k;
-        const uint64_t base = ((uint64_t)li * nq + q) * k;
-        const uint64_t id = ids[base + pi];
+        const uint64_t base_i = (uint64_t)li * list_stride_ids + (uint64_t)q * k;
+        const uint64_t base_s = (uint64_t)li * list_stride_scores + (uint64_t)q * k;
+        const uint64_t id = ids[base_i + pi];
         if (id == UINT64_MAX) continue;
-        const float sc = scores[base + pi];
+        const float sc = scores[base_s + pi];
         const uint32_t key = score_key_rt(sc, metric);
         uint32_t rank = pi;
         for (uint32_t m = 0; m < n_lists; ++m) {
             if (m == li) continue;
-            const uint64_t mb = ((uint64_t)m * nq + q) * k;
+            const uint64_t mb_i = (uint64_t)m * list_stride_ids + (uint64_t)q * k;
+            const uint64_t mb_s = (uint64_t)m * list_stride_scores + (uint64_t)q * k;
             uint32_t lo = 0, hi = k;  // first index whose element does NOT rank before (key, id)
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                const uint64_t mid_id = ids[mb + mid];
+                const uint64_t mid_id = ids[mb_i + mid];
                 const bool before = mid_id != UINT64_MAX &&
-                                    ranks_before(score_key_rt(scores[mb + mid], metric), mid_id, key, id);
+                                    ranks_before(score_key_rt(scores[mb_s + mid], metric), mid_id, key, id);
                 if (before) lo = mid + 1; else hi = mid;
             }
             rank += lo;
@@ -562,11 +558,11 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(int metric, const uint6
     }
 }
 
-void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores, uint32_t n_lists,
-                       uint32_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
-                       hipStream_t s) {
+void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores, uint64_t list_stride_ids,
+                       uint64_t list_stride_scores, uint32_t n_lists, uint32_t nq, uint32_t k,
+                       uint64_t* d_out_ids, float* d_out_scores, hipStream_t s) {
     if (!nq || !k) return;
-    merge_topk_kernel<<<nq, 256, 0, s>>>(metric, d_ids, d_scores, n_lists, nq, k, d_out_ids, d_out_scores);
+    merge_topk_kernel<<<nq, 256, 0, s>>>(metric, d_ids, d_scores, list_stride_ids, list_stride_scores, n_lists, nq, k, d_out_ids, d_out_scores);
 }
 
 }  // namespace vrod

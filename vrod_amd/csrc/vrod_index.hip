@@ -426,10 +426,11 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
                 st.scan_flops += 2.0 * nq * (double)(end - lo) * idx->dim;
                 lo = end;
             }
-            launch_list_compact(d_lists, d_counts, cap, (int)nq, idx->metric, kp, d_thr, d_status, s);
+            const bool last = li + 1 == bounds.size();
+            launch_list_compact(d_lists, d_counts, cap, (int)nq, idx->metric, kp, d_thr, d_status,
+                                last ? idx->cand_rows.as<uint32_t>() : nullptr, last ? idx->cand_fast.as<float>() : nullptr,
+                                last ? d_T : nullptr, s);
         }
-        launch_list_to_candidates(d_lists, d_counts, cap, (int)nq, idx->metric, kp, idx->cand_rows.as<uint32_t>(), idx->cand_fast.as<float>(), d_T, s);
-        HIP_TRY(hipMemcpyAsync(d_T, d_thr, (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipGetLastError());
     }
 
@@ -644,7 +645,24 @@ int vrod_merge_topk_device(int device, int metric, const uint64_t* d_ids, const 
     if ((nq && k && n_lists) && (!d_ids || !d_scores || !d_out_ids || !d_out_scores)) return fail(VROD_ERR_INVALID_ARG, "null buffer");
     if (metric != VROD_METRIC_COSINE && metric != VROD_METRIC_L2) return fail(VROD_ERR_INVALID_ARG, "bad metric %d", metric);
     HIP_TRY(hipSetDevice(device));
-    launch_merge_topk(metric, d_ids, d_scores, n_lists, nq, k, d_out_ids, d_out_scores, (hipStream_t)stream);
+    launch_merge_topk(metric, d_ids, d_scores, (uint64_t)nq * k, (uint64_t)nq * k, n_lists, nq, k, d_out_ids, d_out_scores, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return VROD_OK;
+}
+
+int vrod_merge_topk_packed_device(int device, int metric, const void* d_packed, uint32_t n_lists, uint32_t nq,
+                                  uint32_t k, uint64_t* d_out_ids, float* d_out_scores, void* stream) {
+    if ((nq && k && n_lists) && (!d_packed || !d_out_ids || !d_out_scores)) return fail(VROD_ERR_INVALID_ARG, "null buffer");
+    if (metric != VROD_METRIC_COSINE && metric != VROD_METRIC_L2) return fail(VROD_ERR_INVALID_ARG, "bad metric %d", metric);
+    HIP_TRY(hipSetDevice(device));
+    // one rank's block = nq*k ids (u64) followed by nq*k scores (f32): 12*nq*k bytes, 8-B aligned
+    // as long as nq*k is even; the stride is given in elements of each array
+    const uint64_t block_bytes = (uint64_t)nq * k * 12;
+    if (block_bytes % 8 != 0) return fail(VROD_ERR_INVALID_ARG, "nq*k must be even for the packed layout");
+    const uint64_t* ids = (const uint64_t*)d_packed;
+    const float* scores = (const float*)((const char*)d_packed + (uint64_t)nq * k * 8);
+    launch_merge_topk(metric, ids, scores, block_bytes / 8, block_bytes / 4, n_lists, nq, k, d_out_ids, d_out_scores, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return VROD_OK;

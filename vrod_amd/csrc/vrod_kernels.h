@@ -59,17 +59,15 @@ void launch_keys_to_candidates(const uint64_t* d_keys, uint64_t key_ld, uint64_t
 // Sort each list, keep the best `keep`, write thr[q] = keep-th fast score (worst if short),
 // flag overflow (count > cap) in d_status[q] bit 1.
 // A list shorter than `keep` leaves thr[q] unchanged (rows were still left out at that threshold).
+// d_cand_rows != nullptr (last compaction of a search): also emit candidates [nq][keep]
+// (rows, fast scores; ~0u / NaN padding) and T[q] = the threshold every left-out row fails.
 void launch_list_compact(uint2* d_lists, uint32_t* d_counts, uint32_t cap, int nq, int metric,
-                         uint32_t keep, float* d_thr, uint32_t* d_status, hipStream_t s);
+                         uint32_t keep, float* d_thr, uint32_t* d_status, uint32_t* d_cand_rows,
+                         float* d_cand_fast, float* d_T, hipStream_t s);
 // Sample pass: thr[q] = the j-th best of the n_sample fast scores scores[q][0..n_sample)
 // (exact, 3-pass radix select on the order-preserving key).  One block per query.
 void launch_sample_select(const float* d_scores, uint64_t score_ld, uint32_t n_sample, int nq,
                           int metric, uint32_t j, float* d_thr, hipStream_t s);
-// lists (after compaction) -> candidates as above.
-void launch_list_to_candidates(const uint2* d_lists, const uint32_t* d_counts, uint32_t cap, int nq,
-                               int metric, uint32_t kp, uint32_t* d_cand_rows, float* d_cand_fast,
-                               float* d_T, hipStream_t s);
-
 // Final: canonical scores of the kp candidates -> sorted top-k (ids u64 = row + id_offset),
 // certificate per query in d_status bit 0 (1 = NOT certified).
 // The certificate's bound on |fast - canonical| is formed on the device from the max squared
@@ -88,10 +86,11 @@ void launch_keys_to_output(const uint64_t* d_keys, uint64_t n, int metric, uint3
                            uint64_t id_offset, uint64_t* d_out_ids, float* d_out_scores,
                            hipStream_t s);
 
-// Merge n_lists per-shard results into one (list-major input [list][q][k]).
-void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores, uint32_t n_lists,
-                       uint32_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
-                       hipStream_t s);
+// Merge n_lists per-shard results into one. List l's ids start at d_ids + l*list_stride_ids
+// (elements), its scores at d_scores + l*list_stride_scores; each is [nq][k].
+void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores, uint64_t list_stride_ids,
+                       uint64_t list_stride_scores, uint32_t n_lists, uint32_t nq, uint32_t k,
+                       uint64_t* d_out_ids, float* d_out_scores, hipStream_t s);
 
 // ---- kernels_rescore.hip : canonical (oracle-order) scores
 // d_q: [nq][ld] prepared fp32.  Candidates: rows [nq][kp] (~0u = empty slot -> NaN score).

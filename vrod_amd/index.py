@@ -156,6 +156,17 @@ def merge_topk_device(device: int, metric, ids, scores, out_ids=None, out_scores
     return out_ids, out_scores
 
 
+def merge_topk_packed_device(device: int, metric, packed, n_lists: int, nq: int, k: int, out_ids, out_scores):
+    """packed: torch CUDA uint8 buffer of n_lists blocks (shard.alloc_packed layout) -> merged [nq, k]."""
+    import torch
+    L = _lib.load()
+    assert packed.is_contiguous() and packed.numel() == n_lists * 12 * nq * k
+    stream = torch.cuda.current_stream(packed.device).cuda_stream
+    check(L.vrod_merge_topk_packed_device(int(device), _enum(metric, _METRICS, "metric"), packed.data_ptr(), n_lists, nq, k,
+                                          out_ids.data_ptr(), out_scores.data_ptr(), C.c_void_p(stream)))
+    return out_ids, out_scores
+
+
 def synth_rows_device(device: int, seed: int, first_row: int, n: int, dim: int):
     """Synthetic rows generated on the device, returned as a torch tensor [n, dim]."""
     import torch
