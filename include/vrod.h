@@ -71,7 +71,8 @@ typedef struct {
     float total_ms;             /* HIP-event time of the whole device pipeline */
     double scan_bytes;          /* algorithmic corpus bytes the scan launches covered */
     double scan_flops;          /* algorithmic flops (2*Q*N*d) of the scan launches */
-    float max_fast_err;         /* max |fast - canonical| over re-scored candidates */
+    float max_fast_err;         /* max |fast - canonical| over re-scored candidates (relative to
+                                 * |canonical| on the direct-L2 stream path, whose bound is relative) */
     float eps_bound;            /* the certificate's bound on that error */
 } vrod_search_stats;
 

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
             if (row != 0xFFFFFFFFu) {
                 const float c = cand_canon[(uint64_t)q * kp + i];
                 key = make_key(score_key_rt(c, metric), row);
-                const float e = __builtin_fabsf(cand_fast[(uint64_t)q * kp + i] - c);
+                float e = __builtin_fabsf(cand_fast[(uint64_t)q * kp + i] - c);
+                if (eps_mode == 1) e = e / __builtin_fmaxf(__builtin_fabsf(c), 1e-30f);  // relative bound: relative error
                 if (e == e) err = __builtin_fmaxf(err, e);
             }
         }

@@ -458,7 +458,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         memcpy(&qn2, &hflags[1], 4);
         memcpy(&xn2, &hmaxx, 4);
         const float qn = std::sqrt(qn2), xn = std::sqrt(xn2);
-        st.eps_bound = eps_mode == 0 ? eps_c * qn * xn : eps_mode == 1 ? eps_c * 4.0f : eps_c * (qn + xn) * (qn + xn);
+        st.eps_bound = eps_mode == 0 ? eps_c * qn * xn : eps_mode == 1 ? eps_c /* relative */ : eps_c * (qn + xn) * (qn + xn);
     }
     if (hflags[0]) {  // NaN/Inf in the queries: whatever was computed is void
         HIP_TRY(hipMemsetAsync(&idx->flags[0], 0, 4, s));
