@@ -519,10 +519,10 @@ __device__ __forceinline__ bool ranks_before(uint32_t ka, uint64_t ia, uint32_t 
 __global__ __launch_bounds__(256) void merge_topk_kernel(int metric, const uint64_t* __restrict__ ids,
                                                          const float* __restrict__ scores,
                                                          uint64_t list_stride_ids, uint64_t list_stride_scores,
-                                                         uint32_t n_lists, uint32_t nq, uint32_t k,
+                                                         uint32_t n_lists, uint32_t k,
                                                          uint64_t* __restrict__ out_ids,
                                                          float* __restrict__ out_scores) {
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = blockIdx.x;  // gridDim.x == nq
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
         out_ids[(uint64_t)q * k + i] = UINT64_MAX;
         out_scores[(uint64_t)q * k + i] = __uint_as_float(kScoreNoneBits);
@@ -563,7 +563,7 @@ void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores,
                        uint64_t list_stride_scores, uint32_t n_lists, uint32_t nq, uint32_t k,
                        uint64_t* d_out_ids, float* d_out_scores, hipStream_t s) {
     if (!nq || !k) return;
-    merge_topk_kernel<<<nq, 256, 0, s>>>(metric, d_ids, d_scores, list_stride_ids, list_stride_scores, n_lists, nq, k, d_out_ids, d_out_scores);
+    merge_topk_kernel<<<nq, 256, 0, s>>>(metric, d_ids, d_scores, list_stride_ids, list_stride_scores, n_lists, k, d_out_ids, d_out_scores);
 }
 
 }  // namespace vrod

@@ -294,7 +294,12 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
 
     // ---- path
     int path = idx->path;
-    if (path == VROD_PATH_AUTO) path = nq <= 8 ? VROD_PATH_STREAM : VROD_PATH_MFMA;
+    // AUTO routing, measured on MI355X at 2M x 768 (scripts/route_probe.py): the stream scan is
+    // HBM-bound for 1-2 queries and reduction-bound beyond; a bf16 MFMA batch costs the same for
+    // any nq <= 256 and wins from 3 queries up (0.87 vs 0.99 ms; 0.9 vs 3.3 ms at 8); the fp32
+    // MFMA rate is 16x lower, so fp32 stays on the stream scan up to 8 queries (3.4 vs 5.9 ms).
+    if (path == VROD_PATH_AUTO)
+        path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 2u : 8u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
     st.path = path;
 
     if (N == 0) {  // empty corpus: every slot unfilled
