@@ -110,25 +110,32 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const T* __restrict__ 
 #pragma unroll
                     for (int i = 0; i < IT; ++i) v[u][i] = __builtin_nontemporal_load(rp + i * LPR);
                 }
+                float acc[UNROLL][NQ];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    float acc[NQ];
 #pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi) acc[qi] = 0.0f;
+                    for (int qi = 0; qi < NQ; ++qi) acc[u][qi] = 0.0f;
 #pragma unroll
                     for (int i = 0; i < IT; ++i) {
                         const float* qp = q_lds + (pos0 + i * LPR) * EPU;
 #pragma unroll
                         for (int qi = 0; qi < NQ; ++qi)
-                            acc[qi] = unit_accumulate<T, METRIC>(acc[qi], v[u][i], qp + qi * ld);
-                    }
-#pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi) {
-                        float a = acc[qi];
-                        for (int o = LPR >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o);
-                        if (pos0 == s0 + u) keep[qi] = a;
+                            acc[u][qi] = unit_accumulate<T, METRIC>(acc[u][qi], v[u][i], qp + qi * ld);
                     }
                 }
+                // cross-lane sums: all UNROLL*NQ chains advance together through each shuffle step
+                // (one chain at a time is UNROLL*NQ*log2(LPR) dependent LDS round trips)
+                for (int o = LPR >> 1; o > 0; o >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                        for (int qi = 0; qi < NQ; ++qi) acc[u][qi] += __shfl_xor(acc[u][qi], o);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi)
+                        if (pos0 == s0 + u) keep[qi] = acc[u][qi];
             }
         } else {
             for (int s = 0; s < LPR; ++s) {

@@ -294,12 +294,12 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
 
     // ---- path
     int path = idx->path;
-    // AUTO routing, measured on MI355X at 2M x 768 (scripts/route_probe.py): the stream scan is
-    // HBM-bound for 1-2 queries and reduction-bound beyond; a bf16 MFMA batch costs the same for
-    // any nq <= 256 and wins from 3 queries up (0.87 vs 0.99 ms; 0.9 vs 3.3 ms at 8); the fp32
-    // MFMA rate is 16x lower, so fp32 stays on the stream scan up to 8 queries (3.4 vs 5.9 ms).
+    // AUTO routing, measured on MI355X at 2M x 768 (scripts/route_probe.py): the stream scan costs
+    // about one HBM pass per 8 queries (bf16: 0.63 / 0.69 / 2.0 ms at 1 / 4 / 8 queries, fp32:
+    // 1.09 / 1.21 / 1.47 / 2.85 ms at 1 / 4 / 8 / 16); an MFMA batch costs the same for any
+    // nq <= 256 (bf16 0.85 ms, fp32 5.97 ms: the fp32 MFMA rate is 16x lower).
     if (path == VROD_PATH_AUTO)
-        path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 2u : 8u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
+        path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 4u : 32u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
     st.path = path;
 
     if (N == 0) {  // empty corpus: every slot unfilled
