@@ -625,7 +625,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     a.nstrips = 8 * a.strips_per_xcd;
     // pacing only where several work-groups share a strip (one per query block) and one pass each
     a.pace_every = (h.pace && a.nqb > 1 && a.nqb <= a.slots && pace_env > 0) ? (uint32_t)pace_env : 0u;
-    if (a.pace_every) (void)hipMemsetAsync(a.pace, 0, a.nstrips * sizeof(uint32_t), s);
+    if (a.pace_every && !h.pace_is_zero) (void)hipMemsetAsync(a.pace, 0, a.nstrips * sizeof(uint32_t), s);
     static const bool simple = [] { const char* e = getenv("VROD_MFMA_SIMPLE"); return e && e[0] == '1'; }();
 #define VROD_MFMA(KERNEL, TT, MM)                                                                           \
     do {                                                                                                    \

@@ -155,8 +155,18 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
                                                            uint32_t ld, int round_bf16, float* __restrict__ out_f32,
                                                            bf16_t* __restrict__ out_bf16, float* __restrict__ qn2,
                                                            uint32_t* __restrict__ bad_flag,
-                                                           uint32_t* __restrict__ max_bits) {
+                                                           uint32_t* __restrict__ max_bits, QueryInit init) {
     extern __shared__ __attribute__((aligned(16))) float row[];  // [dim]
+    // per-search state, reset here instead of by separate memset launches
+    if (threadIdx.x == 0) {
+        init.status[blockIdx.x] = 0u;
+        if (init.counts) init.counts[blockIdx.x] = 0u;
+        if (init.thr) init.thr[blockIdx.x] = __uint_as_float(blockIdx.x < nq ? init.thr_live_bits : init.thr_pad_bits);
+    }
+    if (blockIdx.x == 0 && init.zero_words)
+        for (uint32_t i = threadIdx.x; i < init.n_zero_words; i += 256) init.zero_words[i] = 0u;
+    if (blockIdx.x == 0 && init.zero_words2)
+        for (uint32_t i = threadIdx.x; i < init.n_zero_words2; i += 256) init.zero_words2[i] = 0u;
     __shared__ double s_nrm;
     __shared__ float s_part[4];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -237,14 +247,14 @@ void launch_prepare_rows(const float* d_in, uint64_t n, uint32_t dim, uint32_t l
 
 void launch_prep_queries(const float* d_in, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t ld, int metric,
                          int dtype, float* d_out_f32, void* d_out_bf16, float* d_qn2, uint32_t* d_bad_flag,
-                         uint32_t* d_max_bits, hipStream_t s) {
+                         uint32_t* d_max_bits, const QueryInit& init, hipStream_t s) {
     if (!nq_pad) return;
     const size_t lds = (size_t)dim * sizeof(float);
     const int rb = dtype == DT_BF16;
     if (metric == M_COSINE)
-        prep_queries_kernel<true><<<nq_pad, 256, lds, s>>>(d_in, nq, dim, ld, rb, d_out_f32, (bf16_t*)d_out_bf16, d_qn2, d_bad_flag, d_max_bits);
+        prep_queries_kernel<true><<<nq_pad, 256, lds, s>>>(d_in, nq, dim, ld, rb, d_out_f32, (bf16_t*)d_out_bf16, d_qn2, d_bad_flag, d_max_bits, init);
     else
-        prep_queries_kernel<false><<<nq_pad, 256, lds, s>>>(d_in, nq, dim, ld, rb, d_out_f32, (bf16_t*)d_out_bf16, d_qn2, d_bad_flag, d_max_bits);
+        prep_queries_kernel<false><<<nq_pad, 256, lds, s>>>(d_in, nq, dim, ld, rb, d_out_f32, (bf16_t*)d_out_bf16, d_qn2, d_bad_flag, d_max_bits, init);
 }
 
 void launch_row_fastnorm(const void* d_rows, int dtype, uint64_t n, uint32_t ld, float* d_xn2,

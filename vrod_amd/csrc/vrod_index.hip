@@ -99,6 +99,8 @@ struct vrod_index {
     DevBuf cand_rows, cand_fast, cand_canon, out_ids, out_scores;
     uint32_t* flags = nullptr;  // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits
     std::vector<hipEvent_t> ev;
+    uint32_t* h_readback = nullptr;   // pinned host block: status[nq] + 4 scalars, one D2H per search
+    size_t h_readback_words = 0;
 
     size_t row_bytes() const { return (size_t)ld * esize; }
 };
@@ -321,15 +323,48 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         VROD_TRY(idx->q_lp.ensure((size_t)nq_pad * idx->ld * 2));
         q_lp = idx->q_lp.p;
     }
-    VROD_TRY(idx->small.ensure((size_t)nq_pad * 4 * 4 + 64));  // qnorm2 | T | thr | status
+    VROD_TRY(idx->small.ensure((size_t)nq_pad * 4 * 5 + 64));  // qnorm2 | T | thr | status | readback
     float* d_qn2 = idx->small.as<float>();
     float* d_T = d_qn2 + nq_pad;
     float* d_thr = d_T + nq_pad;
     uint32_t* d_status = (uint32_t*)(d_thr + nq_pad);
-    HIP_TRY(hipMemsetAsync(&idx->flags[1], 0, 8, s));  // max |q|^2 bits, max err bits
-    HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)nq_pad * 4, s));
+    uint32_t* d_readback = d_status + nq_pad;   // [nq + 4]
+    if (idx->h_readback_words < (size_t)nq + 4) {
+        if (idx->h_readback) (void)hipHostFree(idx->h_readback);
+        idx->h_readback = nullptr;
+        idx->h_readback_words = 0;
+        HIP_TRY(hipHostMalloc((void**)&idx->h_readback, ((size_t)nq + 4 + 1024) * 4, hipHostMallocDefault));
+        idx->h_readback_words = (size_t)nq + 4 + 1024;
+    }
+    // the MFMA path's per-query list counters / thresholds live behind the lists; they are reset
+    // by the same launch that prepares the queries (padding queries get the BEST score as
+    // threshold so that they never append)
+    const bool mfma = path == VROD_PATH_MFMA;
+    const uint32_t cap = kSelectChunk;
+    uint2* d_lists = nullptr;
+    uint32_t* d_counts = nullptr;
+    if (mfma) {
+        VROD_TRY(idx->lists.ensure((size_t)nq_pad * cap * 8 + (size_t)nq_pad * 4));
+        d_lists = idx->lists.as<uint2>();
+        d_counts = (uint32_t*)((char*)idx->lists.p + (size_t)nq_pad * cap * 8);
+    }
+    const uint32_t worst_bits = idx->metric == VROD_METRIC_COSINE ? 0xFF800000u : 0x7F800000u;  // -inf / +inf
+    QueryInit qi{};
+    qi.status = d_status;
+    qi.counts = d_counts;
+    qi.thr = mfma ? d_thr : nullptr;
+    qi.thr_live_bits = worst_bits;
+    qi.thr_pad_bits = worst_bits ^ 0x80000000u;
+    qi.zero_words = &idx->flags[1];   // max |q|^2 bits, max err bits
+    qi.n_zero_words = 2;
+    // pacing counters: 8 regions of 192 words behind the scalars, one per scan launch of this search
+    constexpr uint32_t kPaceRegions = 8, kPaceWords = 192;
+    uint32_t* pace_base = idx->flags + 64;
+    qi.zero_words2 = mfma ? pace_base : nullptr;
+    qi.n_zero_words2 = kPaceRegions * kPaceWords;
+    uint32_t pace_launch = 0;
     launch_prep_queries(d_queries_raw, nq, nq_pad, idx->dim, idx->ld, idx->metric, idx->dtype, idx->q_f32.as<float>(),
-                        q_lp, d_qn2, &idx->flags[0], &idx->flags[1], s);
+                        q_lp, d_qn2, &idx->flags[0], &idx->flags[1], qi, s);
     HIP_TRY(hipGetLastError());
 
     const float u = 5.9604645e-8f;  // 2^-24
@@ -382,22 +417,10 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         // (4) keep the best k' of every list.
         if (idx->metric == VROD_METRIC_COSINE) { eps_mode = 0; eps_c = 4.f * idx->dim * u; }
         else { eps_mode = 2; eps_c = 4.f * (idx->dim + 4) * u; }
-        const uint32_t cap = kSelectChunk;
-        VROD_TRY(idx->lists.ensure((size_t)nq_pad * cap * 8 + (size_t)nq_pad * 4));
-        uint2* d_lists = idx->lists.as<uint2>();
-        uint32_t* d_counts = (uint32_t*)((char*)idx->lists.p + (size_t)nq_pad * cap * 8);
-        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nq_pad * 4, s));
-        {   // thr = worst score (nothing filtered) for real queries; padding queries never append
-            const uint32_t worst_bits = idx->metric == VROD_METRIC_COSINE ? 0xFF800000u : 0x7F800000u;  // -inf / +inf
-            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_thr, (int)worst_bits, nq, s));
-            if (nq_pad > nq)
-                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(d_thr + nq), (int)(worst_bits ^ 0x80000000u), nq_pad - nq, s));
-        }
         const void* qmat = idx->dtype == VROD_DTYPE_BF16 ? q_lp : idx->q_f32.p;
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
         a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.metric = idx->metric;
-        a.pace = idx->flags + 64;  // the tail of the 2 KB flags block: room for 448 strips
         std::vector<uint64_t> bounds{N};
         if (N > cap) {
             const uint32_t nqb = nq_pad / 256;
@@ -407,6 +430,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
             VROD_TRY(idx->scores.ensure((size_t)nq_pad * dense_ld * 4));
             MfmaScanArgs d = a;
             d.row_begin = 0; d.row_end = sp.S; d.dense_out = idx->scores.as<float>(); d.dense_ld = dense_ld;
+            d.pace = pace_base; d.pace_is_zero = true; ++pace_launch;
             const size_t e0 = tm.mark();
             launch_scan_mfma(d, idx->dtype, idx->num_cus, s);
             const size_t e1 = tm.mark();
@@ -422,6 +446,9 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
                 // a launch addresses rows relative to its first tile with 24 bits
                 const uint64_t end = std::min<uint64_t>(bounds[li], lo / kRowTile * kRowTile + (1ull << 24));
                 a.row_begin = (uint32_t)lo; a.row_end = (uint32_t)end;
+                a.pace = pace_base + (pace_launch % kPaceRegions) * kPaceWords;
+                a.pace_is_zero = pace_launch < kPaceRegions;   // later launches reuse a region: memset
+                ++pace_launch;
                 const size_t e0 = tm.mark();
                 launch_scan_mfma(a, idx->dtype, idx->num_cus, s);
                 const size_t e1 = tm.mark();
@@ -452,12 +479,14 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         launch_final_topk(idx->cand_rows.as<uint32_t>(), idx->cand_fast.as<float>(), idx->cand_canon.as<float>(), d_T, (int)nq, kp, k,
                           idx->metric, idx->id_offset, eps_mode, eps_c, &idx->flags[1], idx->max_xn2_bits, d_out_ids, d_out_scores,
                           d_status, (float*)&idx->flags[2], s);
+        launch_gather_readback(d_status, nq, idx->flags, idx->max_xn2_bits, d_readback, s);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(hstatus.data(), d_status, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(hflags, idx->flags, 12, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&hmaxx, idx->max_xn2_bits, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(idx->h_readback, d_readback, ((size_t)nq + 4) * 4, hipMemcpyDeviceToHost, s));
         tm.t1 = tm.mark();
         HIP_TRY(hipStreamSynchronize(s));
+        memcpy(hstatus.data(), idx->h_readback, (size_t)nq * 4);
+        memcpy(hflags, idx->h_readback + nq, 12);
+        hmaxx = idx->h_readback[nq + 3];
         memcpy(&st.max_fast_err, &hflags[2], 4);
         float qn2, xn2;
         memcpy(&qn2, &hflags[1], 4);
@@ -536,8 +565,8 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
     do {
         if (hipSetDevice(dev) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipSetDevice failed"); break; }
         if (hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipStreamCreate failed"); break; }
-        if (hipMalloc((void**)&idx->flags, 2048) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
-        if (hipMemset(idx->flags, 0, 2048) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
+        if (hipMalloc((void**)&idx->flags, 8192) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
+        if (hipMemset(idx->flags, 0, 8192) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
         idx->max_xn2_bits = idx->flags + 8;
     } while (0);
     if (rc != VROD_OK) { vrod_index_destroy(idx); return rc; }
@@ -554,6 +583,7 @@ int vrod_index_destroy(vrod_index* idx) {
                       &idx->out_ids, &idx->out_scores})
         b->release();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
+    if (idx->h_readback) (void)hipHostFree(idx->h_readback);
     if (idx->corpus) (void)hipFree(idx->corpus);
     if (idx->xnorm2) (void)hipFree(idx->xnorm2);
     if (idx->flags) (void)hipFree(idx->flags);

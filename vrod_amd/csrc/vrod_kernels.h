@@ -13,9 +13,25 @@ void launch_prepare_rows(const float* d_in, uint64_t n, uint32_t dim, uint32_t l
                          void* d_out_bf16, hipStream_t s);
 // Queries: normalise (COSINE) / round (BF16) / zero-pad to [nq_pad][ld] in ONE launch; also the
 // fast squared norms qn2[nq_pad], the NaN/Inf flag and the max squared norm (float bits).
+// `init`: per-search state the same launch resets (block q: status[q], counts[q], thr[q];
+// block 0: n_zero_words words at zero_words) -- replaces five memset launches.
+struct QueryInit {
+    uint32_t* status;        // [nq_pad] -> 0
+    uint32_t* counts;        // [nq_pad] -> 0 (may be null)
+    float* thr;              // [nq_pad] -> thr_live_bits for q < nq, thr_pad_bits beyond (may be null)
+    uint32_t thr_live_bits, thr_pad_bits;
+    uint32_t* zero_words;    // scalars to clear (may be null)
+    uint32_t n_zero_words;
+    uint32_t* zero_words2;   // a second range (the pacing counters of the coming scan launches)
+    uint32_t n_zero_words2;
+};
 void launch_prep_queries(const float* d_in, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t ld, int metric,
                          int dtype, float* d_out_f32, void* d_out_bf16, float* d_qn2, uint32_t* d_bad_flag,
-                         uint32_t* d_max_bits, hipStream_t s);
+                         uint32_t* d_max_bits, const QueryInit& init, hipStream_t s);
+// tail of a search: status[nq] followed by {bad flag, max |q|^2 bits, max err bits, max |x|^2 bits}
+// gathered into one contiguous block so that the host needs ONE device-to-host copy
+void launch_gather_readback(const uint32_t* d_status, uint32_t nq, const uint32_t* d_flags3, const uint32_t* d_max_xn2,
+                            uint32_t* d_out, hipStream_t s);
 void launch_row_fastnorm(const void* d_rows, int dtype, uint64_t n, uint32_t ld, float* d_xn2,
                          uint32_t* d_max_bits, hipStream_t s);
 void launch_rows_get(const void* d_rows, int dtype, uint64_t n, uint32_t dim, uint32_t ld,
@@ -116,7 +132,8 @@ struct MfmaScanArgs {
     uint32_t row_begin;     // appends are limited to rows [row_begin, row_end); the launch
     uint32_t row_end;       // starts at the 256-row tile containing row_begin
     int metric;
-    uint32_t* pace;         // >= 64 words of scratch for the sibling pacing counters (may be null)
+    uint32_t* pace;         // >= 128 words for the sibling pacing counters (may be null)
+    bool pace_is_zero;      // the caller already cleared them (else the launcher issues a memset)
     float* dense_out;       // non-null: sample pass, write every fast score [nq_pad][dense_ld]
     uint32_t dense_ld;      // (column = row - row_begin; multiple of 256)
 };
