@@ -362,6 +362,12 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
     uint32_t* pace_base = idx->flags + 64;
     qi.zero_words2 = mfma ? pace_base : nullptr;
     qi.n_zero_words2 = kPaceRegions * kPaceWords;
+    const size_t hist_words = 8 * 4096 + 8;   // stream path: [8][<=4096] bin counters + 8 key counters
+    if (path == VROD_PATH_STREAM) {
+        VROD_TRY(idx->hist.ensure(hist_words * 4));
+        qi.zero_words2 = idx->hist.as<uint32_t>();   // first pass of 8 queries: cleared by the prep launch
+        qi.n_zero_words2 = (uint32_t)hist_words;
+    }
     uint32_t pace_launch = 0;
     launch_prep_queries(d_queries_raw, nq, nq_pad, idx->dim, idx->ld, idx->metric, idx->dtype, idx->q_f32.as<float>(),
                         q_lp, d_qn2, &idx->flags[0], &idx->flags[1], qi, s);
@@ -384,9 +390,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         else { eps_mode = 1; eps_c = 4.f * (idx->dim + 2) * u; }
         const uint64_t score_ld = round_up(N, 64);
         VROD_TRY(idx->scores.ensure((size_t)8 * score_ld * 4));
-        // radix select, pass 1 fused into the scan: [8][<=4096] bin counters + 8 key counters
-        const size_t hist_words = 8 * 4096 + 8;
-        VROD_TRY(idx->hist.ensure(hist_words * 4));
+        // radix select, pass 1 fused into the scan (histogram buffer prepared above)
         VROD_TRY(idx->keys_a.ensure((size_t)8 * kSelectChunk * 8));
         uint32_t* d_hist = idx->hist.as<uint32_t>();
         uint32_t* d_cnt = d_hist + 8 * 4096;
@@ -394,7 +398,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
             const int nqc = (int)std::min<uint32_t>(8, nq - q0);
             int nqp = 1;
             while (nqp < nqc) nqp <<= 1;
-            HIP_TRY(hipMemsetAsync(d_hist, 0, hist_words * 4, s));
+            if (q0 > 0) HIP_TRY(hipMemsetAsync(d_hist, 0, hist_words * 4, s));
             const size_t a = tm.mark();
             launch_scan_stream(idx->corpus, idx->dtype, idx->metric, idx->ld, N,
                                idx->q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, idx->scores.as<float>(), score_ld,
