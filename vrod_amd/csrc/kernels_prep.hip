@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void row_fastnorm_kernel(const T* __restrict__
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint32_t units = ld * (uint32_t)sizeof(T) / 16;
+    float wave_max = 0.0f;   // one atomic per wave, not per row (every row hits the same address)
     for (uint64_t r = wave; r < n; r += nwaves) {
         const u32x4* x = reinterpret_cast<const u32x4*>(rows + r * (uint64_t)ld);
         float s = 0.0f;
@@ -124,11 +125,10 @@ __global__ __launch_bounds__(256) void row_fastnorm_kernel(const T* __restrict__
             }
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) {
-            xn2[r] = s;
-            atomicMax(max_bits, __float_as_uint(s));  // s >= 0: uint order == float order
-        }
+        if (lane == 0) xn2[r] = s;
+        wave_max = __builtin_fmaxf(wave_max, s);
     }
+    if (lane == 0 && wave_max > 0.0f) atomicMax(max_bits, __float_as_uint(wave_max));  // >= 0: uint order == float order
 }
 
 // ------------------------------------------------------------------ widen stored rows back to fp32
