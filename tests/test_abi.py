@@ -81,3 +81,12 @@ def test_product_never_imports_the_oracle():
                 assert '#include "vrod_oracle.h"' not in txt and "dlopen" not in txt, os.path.join(dp, f)
                 assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
                 assert "libvrod_oracle" not in txt, os.path.join(dp, f)
+
+
+def test_rust_binding_crate_declares_exactly_the_abi():
+    """bindings/rust (source only: no rustc in the image) must stay in sync with include/vrod.h."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    ext = src[src.index('extern "C" {'):]
+    ext = ext[:ext.index("\n}\n")]
+    rust = sorted(set(re.findall(r"pub fn (vrod_[a-z_0-9]+)\s*\(", ext)))
+    assert rust == declared_symbols()

@@ -281,3 +281,11 @@ def test_merge_topk_packed_device(va, oracle):
     va.merge_topk_packed_device(0, "l2", gathered, G, 6, k, mi, ms)
     oi, osc = oracle.search(raw, rq, k, 0, 1)
     assert_same(mi.cpu().numpy().view(np.uint64), ms.cpu().numpy(), oi, osc, "packed merge")
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_max_k(va, oracle, path):
+    """k = VROD_MAX_K (3584): k' = 4032 candidates per query, the widest select windows."""
+    raw = oracle.synth_rows(1, 0, 30000, 64, threads=8)
+    rq = oracle.synth_rows(2, 0, 3, 64)
+    run_case(va, oracle, raw, rq, va.MAX_K, "f32", "cosine", path)
