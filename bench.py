@@ -59,13 +59,14 @@ def parse():
     return ap.parse_args()
 
 
-def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev):
+def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, collective=None):
     """Run `steps` batches; returns accumulated library stats of this rank."""
     from vrod_amd.shard import all_gather_packed, alloc_packed
     nq, k = wl["nq"], wl["k"]
     # this rank's results live in one packed block (ids | scores): the exchange is ONE all-gather
     packed, oi, osc = alloc_packed(nq, k, dev)
-    if world > 1:
+    collective = world > 1 if collective is None else collective
+    if collective:
         gathered = torch.empty(world * packed.numel(), dtype=torch.uint8, device=dev)
         mi = torch.empty((nq, k), dtype=torch.int64, device=dev)
         ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
@@ -73,7 +74,7 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev):
     for s in range(steps):
         ix.search_synthetic_device(QUERY_SEED, (first_step + s) * nq, nq, k, oi, osc)
         st = ix.last_stats()
-        if world > 1:
+        if collective:
             # per-shard top-k -> every rank (RCCL all-gather over xGMI), then the exact merge
             all_gather_packed(dist, packed, gathered)
             va.merge_topk_packed_device(dev.index, wl["metric"], gathered, world, nq, k, mi, ms)
@@ -85,7 +86,7 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev):
         acc["total_ms"] += st["total_ms"]
         acc["max_err"] = max(acc["max_err"], st["max_fast_err"])
         acc["eps"] = st["eps_bound"]
-    final = (mi, ms) if world > 1 else (oi, osc)
+    final = (mi, ms) if collective else (oi, osc)
     return acc, final
 
 
@@ -149,6 +150,11 @@ def cpu_baseline(wl, va, torch, dev, n_total):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line.  Native libraries write there too (RCCL prints a
+    # version banner at communicator creation), so fd 1 points at stderr until the final print.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -161,8 +167,12 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # VROD_BENCH_FORCE_COLLECTIVE=1: run the all-gather + merge even with one rank (rehearsal of
+    # the N>1 code path on a 1-GPU box; the exchange is then part of the timed step)
+    force_coll = os.environ.get("VROD_BENCH_FORCE_COLLECTIVE") == "1"
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import vrod_amd as va
@@ -179,14 +189,15 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 or force_coll:
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(dev)
 
-    run_steps(ix, wl, args.warmup, 0, world, rank, dist, va, torch, dev)
+    coll = world > 1 or force_coll
+    run_steps(ix, wl, args.warmup, 0, world, rank, dist, va, torch, dev, coll)
     fence()
     t0 = time.perf_counter()
-    acc, final = run_steps(ix, wl, args.steps, args.warmup, world, rank, dist, va, torch, dev)
+    acc, final = run_steps(ix, wl, args.steps, args.warmup, world, rank, dist, va, torch, dev, coll)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -270,8 +281,11 @@ def main():
                              "frac": round(gbps / PEAK["hbm"][0], 4), "kernel": "scan_stream_kernel",
                              "avg_launch_ms": round(a2["scan_ms"] / max(a2["launches"], 1), 4)}}
             hx.close()
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if world > 1 or force_coll:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
