@@ -7,6 +7,8 @@
 
 One "step" = one batch of queries through the whole search (fast scan -> candidates ->
 canonical re-score -> certified top-k), corpus resident in HBM before the timed region.
+Two batches are in flight (begin(s+1) is enqueued before end(s)); every one of the K batches
+is begun, completed, exchanged and merged inside the timed region.
 Default workload = the configuration BASELINE.json's metric is quoted on:
 10M x 768 bf16 cosine, batch 1024, top-10 ("cfg3").  With N GPUs the 10M rows are sharded
 into contiguous ranges (strong scaling), every rank scans its shard for the same batch and
@@ -60,24 +62,45 @@ def parse():
 
 
 def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, collective=None):
-    """Run `steps` batches; returns accumulated library stats of this rank."""
+    """Run `steps` batches; returns accumulated library stats of this rank.
+
+    Two batches are in flight (vrod_search_begin_* / vrod_search_end): batch s+1 is enqueued on
+    the library's stream before batch s is completed, so the device goes from one scan straight
+    into the next while the host reads batch s's certificate verdicts and this rank's top-k of
+    batch s is all-gathered (RCCL) and merged on torch's stream.  Every batch that is begun is
+    ended, exchanged and merged inside this function: the pipeline is drained before it returns.
+    VROD_BENCH_PIPELINE=0 runs the batches strictly one after the other instead.
+    """
     from vrod_amd.shard import all_gather_packed, alloc_packed
     nq, k = wl["nq"], wl["k"]
+    depth = 1 if os.environ.get("VROD_BENCH_PIPELINE") == "0" else 2
     # this rank's results live in one packed block (ids | scores): the exchange is ONE all-gather
-    packed, oi, osc = alloc_packed(nq, k, dev)
+    bufs = [alloc_packed(nq, k, dev) for _ in range(depth)]
     collective = world > 1 if collective is None else collective
     if collective:
-        gathered = torch.empty(world * packed.numel(), dtype=torch.uint8, device=dev)
+        gathered = torch.empty(world * bufs[0][0].numel(), dtype=torch.uint8, device=dev)
         mi = torch.empty((nq, k), dtype=torch.int64, device=dev)
         ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
     acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, total_ms=0.0, max_err=0.0, eps=0.0)
+
+    def begin(s):
+        _, oi, osc = bufs[s % depth]
+        ix.search_begin_synthetic_device(QUERY_SEED, (first_step + s) * nq, nq, k, oi, osc)
+
+    if steps > 0:
+        begin(0)
     for s in range(steps):
-        ix.search_synthetic_device(QUERY_SEED, (first_step + s) * nq, nq, k, oi, osc)
+        if depth == 2 and s + 1 < steps:
+            begin(s + 1)
+        ix.search_end()
         st = ix.last_stats()
+        packed, oi, osc = bufs[s % depth]
         if collective:
             # per-shard top-k -> every rank (RCCL all-gather over xGMI), then the exact merge
             all_gather_packed(dist, packed, gathered)
             va.merge_topk_packed_device(dev.index, wl["metric"], gathered, world, nq, k, mi, ms)
+        if depth == 1 and s + 1 < steps:
+            begin(s + 1)
         acc["scan_ms"] += st["scan_ms"]
         acc["scan_flops"] += st["scan_flops"]
         acc["scan_bytes"] += st["scan_bytes"]
@@ -86,7 +109,7 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         acc["total_ms"] += st["total_ms"]
         acc["max_err"] = max(acc["max_err"], st["max_fast_err"])
         acc["eps"] = st["eps_bound"]
-    final = (mi, ms) if collective else (oi, osc)
+    final = (mi, ms) if collective else (bufs[(steps - 1) % depth][1], bufs[(steps - 1) % depth][2])
     return acc, final
 
 
@@ -250,7 +273,8 @@ def main():
             "config": {"workload": f"{args.workload}: {n_total} x {wl['dim']} {wl['dtype']} {wl['metric']}, batch={nq}, top-{wl['k']}",
                        "rows_total": n_total, "rows_per_gpu": hi - lo, "dim": wl["dim"], "batch": nq, "k": wl["k"],
                        "metric": wl["metric"], "parallelism": f"row-shard x{world}, RCCL all-gather of per-shard top-k" if world > 1 else "single GPU",
-                       "corpus_seed": CORPUS_SEED, "query_seed": QUERY_SEED},
+                       "corpus_seed": CORPUS_SEED, "query_seed": QUERY_SEED,
+                       "batches_in_flight": 1 if os.environ.get("VROD_BENCH_PIPELINE") == "0" else 2},
             "roofline": roofline,
             "exactness": {"certificate_fallback_queries": fallback_total, "max_fast_err": acc["max_err"], "eps_bound": acc["eps"],
                           "note": "ids and score bits equal the CPU oracle by construction (canonical re-score + certificate)"},

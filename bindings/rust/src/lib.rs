@@ -53,6 +53,13 @@ extern "C" {
                               d_out_ids: *mut u64, d_out_scores: *mut f32, stream: *mut c_void) -> c_int;
     pub fn vrod_search_synthetic_device(idx: *mut vrod_index, seed: u64, first_row: u64, nq: u32, k: u32,
                                         d_out_ids: *mut u64, d_out_scores: *mut f32, stream: *mut c_void) -> c_int;
+    pub fn vrod_search_begin_device(idx: *mut vrod_index, d_queries: *const f32, nq: u32, k: u32,
+                                    d_out_ids: *mut u64, d_out_scores: *mut f32, stream: *mut c_void) -> c_int;
+    pub fn vrod_search_begin_synthetic_device(idx: *mut vrod_index, seed: u64, first_row: u64, nq: u32, k: u32,
+                                              d_out_ids: *mut u64, d_out_scores: *mut f32,
+                                              stream: *mut c_void) -> c_int;
+    pub fn vrod_search_end(idx: *mut vrod_index) -> c_int;
+    pub fn vrod_search_pending(idx: *const vrod_index, out_pending: *mut u32) -> c_int;
     pub fn vrod_merge_topk_device(device: c_int, metric: c_int, d_ids: *const u64, d_scores: *const f32,
                                   n_lists: u32, nq: u32, k: u32, d_out_ids: *mut u64,
                                   d_out_scores: *mut f32, stream: *mut c_void) -> c_int;

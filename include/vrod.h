@@ -61,7 +61,7 @@ enum { VROD_METRIC_COSINE = 0, VROD_METRIC_L2 = 1 };
 /* Which fast pass vrod_search uses. AUTO picks by batch size and dtype. */
 enum { VROD_PATH_AUTO = 0, VROD_PATH_STREAM = 1, VROD_PATH_MFMA = 2, VROD_PATH_EXACT = 3 };
 
-/* Counters of the most recent search on a handle (bench.py / tests read these). */
+/* Counters of the most recently COMPLETED search on a handle (bench.py / tests read these). */
 typedef struct {
     uint32_t path;              /* VROD_PATH_* actually taken */
     uint32_t nq, k, kprime;     /* kprime = candidates re-scored per query */
@@ -110,6 +110,24 @@ int vrod_search_device(vrod_index *idx, const float *d_queries, uint32_t nq, uin
 int vrod_search_synthetic_device(vrod_index *idx, uint64_t seed, uint64_t first_row,
                                  uint32_t nq, uint32_t k, uint64_t *d_out_ids,
                                  float *d_out_scores, void *stream);
+/* Pipelined form of vrod_search_device: _begin_ enqueues the whole search on the library's own
+ * stream, ordered after everything `stream` holds at the time of the call, and returns without
+ * waiting for the device; vrod_search_end completes the OLDEST begun search (FIFO) -- when it
+ * returns VROD_OK that search's results are complete in device memory.  At most two searches may
+ * be pending: begin(s+1) before end(s) keeps the device busy while the host, and the caller's
+ * exchange of batch s (all-gather + merge), catch up.  A begun search must be
+ * ended; the queries of a _begin_device call and both output buffers must stay untouched until
+ * then.  While a search is pending every other entry point on the handle that touches the
+ * corpus or the stream fails with VROD_ERR_INVALID_ARG.  Errors that depend on the data (NaN or
+ * Inf in the queries) are reported by vrod_search_end. */
+int vrod_search_begin_device(vrod_index *idx, const float *d_queries, uint32_t nq, uint32_t k,
+                             uint64_t *d_out_ids, float *d_out_scores, void *stream);
+int vrod_search_begin_synthetic_device(vrod_index *idx, uint64_t seed, uint64_t first_row,
+                                       uint32_t nq, uint32_t k, uint64_t *d_out_ids,
+                                       float *d_out_scores, void *stream);
+int vrod_search_end(vrod_index *idx);
+int vrod_search_pending(const vrod_index *idx, uint32_t *out_pending);
+
 /* Merge n_lists per-shard results (device, each nq x k, list-major: [list][q][k]) into
  * one nq x k on `device` -- the step after the RCCL all-gather. */
 int vrod_merge_topk_device(int device, int metric, const uint64_t *d_ids,

@@ -17,6 +17,7 @@ SYMBOLS = [
     "vrod_index_create", "vrod_index_destroy", "vrod_index_reserve", "vrod_index_add",
     "vrod_index_add_synthetic", "vrod_index_count", "vrod_index_set_id_offset",
     "vrod_index_get_rows", "vrod_search", "vrod_search_device", "vrod_search_synthetic_device",
+    "vrod_search_begin_device", "vrod_search_begin_synthetic_device", "vrod_search_end", "vrod_search_pending",
     "vrod_merge_topk_device", "vrod_merge_topk_packed_device", "vrod_index_set_path", "vrod_index_set_profiling",
     "vrod_index_last_stats", "vrod_last_error", "vrod_version", "vrod_synth_rows_device",
 ]
@@ -72,6 +73,10 @@ def load() -> C.CDLL:
     L.vrod_search.argtypes = [vp, vp, u32, u32, vp, vp]
     L.vrod_search_device.argtypes = [vp, vp, u32, u32, vp, vp, vp]
     L.vrod_search_synthetic_device.argtypes = [vp, u64, u64, u32, u32, vp, vp, vp]
+    L.vrod_search_begin_device.argtypes = [vp, vp, u32, u32, vp, vp, vp]
+    L.vrod_search_begin_synthetic_device.argtypes = [vp, u64, u64, u32, u32, vp, vp, vp]
+    L.vrod_search_end.argtypes = [vp]
+    L.vrod_search_pending.argtypes = [vp, C.POINTER(u32)]
     L.vrod_merge_topk_device.argtypes = [i32, i32, vp, vp, u32, u32, u32, vp, vp, vp]
     L.vrod_merge_topk_packed_device.argtypes = [i32, i32, vp, u32, u32, u32, vp, vp, vp]
     L.vrod_index_set_path.argtypes = [vp, i32]

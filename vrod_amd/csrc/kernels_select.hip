@@ -487,14 +487,19 @@ void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
 
 // ------------------------------------------------------------------ readback block
 __global__ __launch_bounds__(256) void gather_readback_kernel(const uint32_t* __restrict__ status, uint32_t nq,
-                                                              const uint32_t* __restrict__ flags3,
+                                                              uint32_t* __restrict__ flags3,
                                                               const uint32_t* __restrict__ max_xn2,
                                                               uint32_t* __restrict__ out) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) out[i] = status[i];
-    if (blockIdx.x == 0 && threadIdx.x < 4) out[nq + threadIdx.x] = threadIdx.x < 3 ? flags3[threadIdx.x] : *max_xn2;
+    if (blockIdx.x == 0 && threadIdx.x < 4) {
+        out[nq + threadIdx.x] = threadIdx.x < 3 ? flags3[threadIdx.x] : *max_xn2;
+        // the bad-value flag is consumed here, so that the next search in the stream (which may be
+        // enqueued before the host has looked at this one) starts from a clean flag
+        if (threadIdx.x == 0) flags3[0] = 0;
+    }
 }
 
-void launch_gather_readback(const uint32_t* d_status, uint32_t nq, const uint32_t* d_flags3, const uint32_t* d_max_xn2,
+void launch_gather_readback(const uint32_t* d_status, uint32_t nq, uint32_t* d_flags3, const uint32_t* d_max_xn2,
                             uint32_t* d_out, hipStream_t s) {
     gather_readback_kernel<<<(nq + 255) / 256 > 0 ? (nq + 255) / 256 : 1, 256, 0, s>>>(d_status, nq, d_flags3, d_max_xn2, d_out);
 }

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -78,6 +79,32 @@ struct DevBuf {
 
 static inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
+// ------------------------------------------------------------------ one search in flight
+// A search is ENQUEUED (every launch up to the D2H of its status block) and later COMPLETED (wait
+// for that copy, read the certificate's verdicts, run the exact path for the rare failures).  Two
+// slots let the caller enqueue search s+1 before it completes search s, so the device never waits
+// for the host between batches and the caller's exchange of batch s (all-gather + merge on its own
+// stream) overlaps the scan of batch s+1.  Everything a completion may still need after the next
+// search has been enqueued lives in the slot; the other workspaces are shared and stream-ordered.
+struct Pending {
+    bool active = false;
+    bool trivial = false;          // nq == 0 or empty corpus: the outputs are already final
+    uint32_t nq = 0, k = 0, kp = 0;
+    int path = 0, eps_mode = 0;
+    float eps_c = 0.f;
+    uint64_t N = 0;
+    uint64_t* out_ids = nullptr;
+    float* out_scores = nullptr;
+    DevBuf q_f32;                  // prepared queries (the exact path re-reads them)
+    uint32_t* h_readback = nullptr;   // pinned host block: status[nq] + 4 scalars, one D2H per search
+    size_t h_readback_words = 0;
+    hipEvent_t done = nullptr;     // recorded behind the D2H
+    std::vector<hipEvent_t> ev;    // profiling events
+    size_t ev_used = 0, t0 = 0, t1 = 0;
+    std::vector<std::pair<size_t, size_t>> scan_pairs;
+    vrod_search_stats st{};
+};
+
 // ------------------------------------------------------------------ the index
 struct vrod_index {
     int device = 0;
@@ -95,12 +122,14 @@ struct vrod_index {
     vrod_search_stats stats{};
 
     // workspaces
-    DevBuf raw_stage, nrm_ws, q_raw, q_f32, q_lp, scores, keys_a, keys_b, lists, small, hist;
+    DevBuf raw_stage, nrm_ws, q_raw, q_lp, scores, keys_a, keys_b, lists, small, hist;
     DevBuf cand_rows, cand_fast, cand_canon, out_ids, out_scores;
     uint32_t* flags = nullptr;  // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits
-    std::vector<hipEvent_t> ev;
-    uint32_t* h_readback = nullptr;   // pinned host block: status[nq] + 4 scalars, one D2H per search
-    size_t h_readback_words = 0;
+    Pending slot[2];
+    uint32_t n_begun = 0, n_ended = 0;   // searches enqueued / completed: slot = counter & 1
+    hipEvent_t caller_ev = nullptr;      // orders the caller's stream before ours
+
+    uint32_t n_pending() const { return n_begun - n_ended; }
 
     size_t row_bytes() const { return (size_t)ld * esize; }
 };
@@ -199,23 +228,21 @@ static int index_add(vrod_index* idx, const float* rows, uint64_t n, bool synthe
 // ------------------------------------------------------------------ search pipeline
 struct Timer {
     vrod_index* idx;
-    size_t used = 0;
-    std::vector<std::pair<size_t, size_t>> scan_pairs;
-    size_t t0 = 0, t1 = 0;
-    explicit Timer(vrod_index* i) : idx(i) {}
+    Pending& P;
+    Timer(vrod_index* i, Pending& p) : idx(i), P(p) {}
     size_t mark() {
         if (!idx->profiling) return 0;
-        if (used == idx->ev.size()) {
+        if (P.ev_used == P.ev.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return 0;
-            idx->ev.push_back(e);
+            P.ev.push_back(e);
         }
-        (void)hipEventRecord(idx->ev[used], idx->stream);
-        return used++;
+        (void)hipEventRecord(P.ev[P.ev_used], idx->stream);
+        return P.ev_used++;
     }
     float ms(size_t a, size_t b) {
         float m = 0.f;
-        if (idx->profiling && a < used && b < used) (void)hipEventElapsedTime(&m, idx->ev[a], idx->ev[b]);
+        if (idx->profiling && a < P.ev_used && b < P.ev_used) (void)hipEventElapsedTime(&m, P.ev[a], P.ev[b]);
         return m;
     }
 };
@@ -279,20 +306,26 @@ static StagePlan plan_stages(uint64_t N, uint32_t kp, uint32_t cap, uint32_t max
     return p;
 }
 
-static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, uint32_t k,
-                      uint64_t* d_out_ids, float* d_out_scores) {
-    vrod_search_stats& st = idx->stats;
+// Enqueue one search into slot P: every launch up to the D2H of the status block.  Returns
+// without waiting for the device (except on the trivial empty-corpus case).
+static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_raw, uint32_t nq, uint32_t k,
+                          uint64_t* d_out_ids, float* d_out_scores) {
+    vrod_search_stats& st = P.st;
     st = vrod_search_stats{};
     st.nq = nq;
     st.k = k;
+    P.nq = nq; P.k = k; P.out_ids = d_out_ids; P.out_scores = d_out_scores;
+    P.trivial = true;
+    P.ev_used = 0; P.t0 = P.t1 = 0; P.scan_pairs.clear();
     if (!nq) return VROD_OK;
     hipStream_t s = idx->stream;
-    Timer tm(idx);
-    tm.t0 = tm.mark();
+    Timer tm(idx, P);
+    P.t0 = tm.mark();
 
     const uint64_t N = idx->count;
     const uint32_t kp = choose_kp(N, k);
     st.kprime = kp;
+    P.N = N; P.kp = kp;
 
     // ---- path
     int path = idx->path;
@@ -303,6 +336,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
     if (path == VROD_PATH_AUTO)
         path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 4u : 32u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
     st.path = path;
+    P.path = path;
 
     if (N == 0) {  // empty corpus: every slot unfilled
         std::vector<uint64_t> hi((size_t)nq * k, UINT64_MAX);
@@ -317,7 +351,9 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
     // fast norms, NaN/Inf flag, max |q|^2.  No host round trip: the certificate forms its bound
     // on the device and the flag is read with the results.
     const uint32_t nq_pad = (uint32_t)round_up(nq, path == VROD_PATH_MFMA ? 256 : 8);
-    VROD_TRY(idx->q_f32.ensure((size_t)nq_pad * idx->ld * 4));
+    P.trivial = false;
+    if (!P.done) HIP_TRY(hipEventCreateWithFlags(&P.done, hipEventDisableTiming));
+    VROD_TRY(P.q_f32.ensure((size_t)nq_pad * idx->ld * 4));
     void* q_lp = nullptr;
     if (idx->dtype == VROD_DTYPE_BF16) {
         VROD_TRY(idx->q_lp.ensure((size_t)nq_pad * idx->ld * 2));
@@ -329,12 +365,12 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
     float* d_thr = d_T + nq_pad;
     uint32_t* d_status = (uint32_t*)(d_thr + nq_pad);
     uint32_t* d_readback = d_status + nq_pad;   // [nq + 4]
-    if (idx->h_readback_words < (size_t)nq + 4) {
-        if (idx->h_readback) (void)hipHostFree(idx->h_readback);
-        idx->h_readback = nullptr;
-        idx->h_readback_words = 0;
-        HIP_TRY(hipHostMalloc((void**)&idx->h_readback, ((size_t)nq + 4 + 1024) * 4, hipHostMallocDefault));
-        idx->h_readback_words = (size_t)nq + 4 + 1024;
+    if (P.h_readback_words < (size_t)nq + 4) {
+        if (P.h_readback) (void)hipHostFree(P.h_readback);
+        P.h_readback = nullptr;
+        P.h_readback_words = 0;
+        HIP_TRY(hipHostMalloc((void**)&P.h_readback, ((size_t)nq + 4 + 1024) * 4, hipHostMallocDefault));
+        P.h_readback_words = (size_t)nq + 4 + 1024;
     }
     // the MFMA path's per-query list counters / thresholds live behind the lists; they are reset
     // by the same launch that prepares the queries (padding queries get the BEST score as
@@ -369,7 +405,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         qi.n_zero_words2 = (uint32_t)hist_words;
     }
     uint32_t pace_launch = 0;
-    launch_prep_queries(d_queries_raw, nq, nq_pad, idx->dim, idx->ld, idx->metric, idx->dtype, idx->q_f32.as<float>(),
+    launch_prep_queries(d_queries_raw, nq, nq_pad, idx->dim, idx->ld, idx->metric, idx->dtype, P.q_f32.as<float>(),
                         q_lp, d_qn2, &idx->flags[0], &idx->flags[1], qi, s);
     HIP_TRY(hipGetLastError());
 
@@ -381,7 +417,6 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
     VROD_TRY(idx->cand_fast.ensure((size_t)nq * kp * 4));
     VROD_TRY(idx->cand_canon.ensure((size_t)nq * kp * 4));
 
-    std::vector<uint32_t> hstatus(nq, 0);
     const double row_bytes_alg = (double)idx->ld * idx->esize;
 
     if (path == VROD_PATH_STREAM) {
@@ -401,10 +436,10 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
             if (q0 > 0) HIP_TRY(hipMemsetAsync(d_hist, 0, hist_words * 4, s));
             const size_t a = tm.mark();
             launch_scan_stream(idx->corpus, idx->dtype, idx->metric, idx->ld, N,
-                               idx->q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, idx->scores.as<float>(), score_ld,
+                               P.q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, idx->scores.as<float>(), score_ld,
                                d_hist, kp, s);
             const size_t b = tm.mark();
-            tm.scan_pairs.push_back({a, b});
+            P.scan_pairs.push_back({a, b});
             st.scan_launches++;
             st.scan_bytes += (double)N * row_bytes_alg;
             st.scan_flops += 2.0 * nqc * (double)N * idx->dim;
@@ -421,7 +456,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         // (4) keep the best k' of every list.
         if (idx->metric == VROD_METRIC_COSINE) { eps_mode = 0; eps_c = 4.f * idx->dim * u; }
         else { eps_mode = 2; eps_c = 4.f * (idx->dim + 4) * u; }
-        const void* qmat = idx->dtype == VROD_DTYPE_BF16 ? q_lp : idx->q_f32.p;
+        const void* qmat = idx->dtype == VROD_DTYPE_BF16 ? q_lp : P.q_f32.p;
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
         a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.metric = idx->metric;
@@ -438,7 +473,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
             const size_t e0 = tm.mark();
             launch_scan_mfma(d, idx->dtype, idx->num_cus, s);
             const size_t e1 = tm.mark();
-            tm.scan_pairs.push_back({e0, e1});
+            P.scan_pairs.push_back({e0, e1});
             st.scan_launches++;
             st.scan_bytes += (double)dense_ld * row_bytes_alg;
             st.scan_flops += 2.0 * nq * (double)sp.S * idx->dim;
@@ -456,7 +491,7 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
                 const size_t e0 = tm.mark();
                 launch_scan_mfma(a, idx->dtype, idx->num_cus, s);
                 const size_t e1 = tm.mark();
-                tm.scan_pairs.push_back({e0, e1});
+                P.scan_pairs.push_back({e0, e1});
                 st.scan_launches++;
                 st.scan_bytes += (double)(end - lo / kRowTile * kRowTile) * row_bytes_alg;
                 st.scan_flops += 2.0 * nq * (double)(end - lo) * idx->dim;
@@ -470,27 +505,46 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         HIP_TRY(hipGetLastError());
     }
 
-    uint32_t hflags[3] = {0, 0, 0};
-    uint32_t hmaxx = 0;
-    if (path == VROD_PATH_EXACT) {
-        std::fill(hstatus.begin(), hstatus.end(), 1u);
-        HIP_TRY(hipMemcpyAsync(hflags, idx->flags, 12, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    } else {
+    P.eps_mode = eps_mode;
+    P.eps_c = eps_c;
+    if (path != VROD_PATH_EXACT) {
         // -------- canonical re-score + final ordering + certificate
-        launch_rescore_candidates(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, idx->q_f32.as<float>(), (int)nq,
+        launch_rescore_candidates(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.q_f32.as<float>(), (int)nq,
                                   idx->cand_rows.as<uint32_t>(), kp, idx->cand_canon.as<float>(), s);
         launch_final_topk(idx->cand_rows.as<uint32_t>(), idx->cand_fast.as<float>(), idx->cand_canon.as<float>(), d_T, (int)nq, kp, k,
                           idx->metric, idx->id_offset, eps_mode, eps_c, &idx->flags[1], idx->max_xn2_bits, d_out_ids, d_out_scores,
                           d_status, (float*)&idx->flags[2], s);
-        launch_gather_readback(d_status, nq, idx->flags, idx->max_xn2_bits, d_readback, s);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(idx->h_readback, d_readback, ((size_t)nq + 4) * 4, hipMemcpyDeviceToHost, s));
-        tm.t1 = tm.mark();
-        HIP_TRY(hipStreamSynchronize(s));
-        memcpy(hstatus.data(), idx->h_readback, (size_t)nq * 4);
-        memcpy(hflags, idx->h_readback + nq, 12);
-        hmaxx = idx->h_readback[nq + 3];
+    }
+    launch_gather_readback(d_status, nq, idx->flags, idx->max_xn2_bits, d_readback, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(P.h_readback, d_readback, ((size_t)nq + 4) * 4, hipMemcpyDeviceToHost, s));
+    P.t1 = tm.mark();
+    HIP_TRY(hipEventRecord(P.done, s));
+    return VROD_OK;
+}
+
+// Complete the search in slot P: wait for its status block, then run the exact path for the
+// queries whose certificate failed (enqueued behind whatever the stream holds by now).
+static int search_complete(vrod_index* idx, Pending& P) {
+    vrod_search_stats& st = P.st;
+    hipStream_t s = idx->stream;
+    Timer tm(idx, P);
+    const uint32_t nq = P.nq, k = P.k;
+    const uint64_t N = P.N;
+    if (P.trivial) {
+        idx->stats = st;
+        return VROD_OK;
+    }
+    HIP_TRY(hipEventSynchronize(P.done));
+    std::vector<uint32_t> hstatus(P.h_readback, P.h_readback + nq);
+    uint32_t hflags[3];
+    memcpy(hflags, P.h_readback + nq, 12);
+    const uint32_t hmaxx = P.h_readback[nq + 3];
+    if (P.path == VROD_PATH_EXACT) {
+        std::fill(hstatus.begin(), hstatus.end(), 1u);
+    } else {
+        const int eps_mode = P.eps_mode;
+        const float eps_c = P.eps_c;
         memcpy(&st.max_fast_err, &hflags[2], 4);
         float qn2, xn2;
         memcpy(&qn2, &hflags[1], 4);
@@ -498,9 +552,8 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         const float qn = std::sqrt(qn2), xn = std::sqrt(xn2);
         st.eps_bound = eps_mode == 0 ? eps_c * qn * xn : eps_mode == 1 ? eps_c /* relative */ : eps_c * (qn + xn) * (qn + xn);
     }
-    if (hflags[0]) {  // NaN/Inf in the queries: whatever was computed is void
-        HIP_TRY(hipMemsetAsync(&idx->flags[0], 0, 4, s));
-        HIP_TRY(hipStreamSynchronize(s));
+    if (hflags[0]) {  // NaN/Inf in the queries: whatever was computed is void (flag reset on device)
+        idx->stats = st;
         return fail(VROD_ERR_INVALID_VALUE, "queries contain NaN or Inf");
     }
 
@@ -510,22 +563,69 @@ static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, 
         st.fallback_queries++;
         const uint64_t score_ld = round_up(N, 64);
         VROD_TRY(idx->scores.ensure((size_t)score_ld * 4));
-        launch_rescore_all(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, idx->q_f32.as<float>() + (size_t)qi * idx->ld, N,
+        launch_rescore_all(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.q_f32.as<float>() + (size_t)qi * idx->ld, N,
                            idx->scores.as<float>(), s);
         const uint32_t kx = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(k, N), kSelectChunk / 2);
         const uint64_t* keys; uint64_t kld, kn;
         VROD_TRY(select_chain(idx, idx->scores.as<float>(), score_ld, N, 1, kx, &keys, &kld, &kn));
-        launch_keys_to_output(keys, kn, idx->metric, k, idx->id_offset, d_out_ids + (size_t)qi * k, d_out_scores + (size_t)qi * k, s);
+        launch_keys_to_output(keys, kn, idx->metric, k, idx->id_offset, P.out_ids + (size_t)qi * k, P.out_scores + (size_t)qi * k, s);
         HIP_TRY(hipGetLastError());
     }
-    if (st.fallback_queries || path == VROD_PATH_EXACT) {
-        tm.t1 = tm.mark();
+    if (st.fallback_queries) {
+        P.t1 = tm.mark();
         HIP_TRY(hipStreamSynchronize(s));
     }
     if (idx->profiling) {
-        for (auto& pr : tm.scan_pairs) st.scan_ms += tm.ms(pr.first, pr.second);
-        st.total_ms = tm.ms(tm.t0, tm.t1);
+        for (auto& pr : P.scan_pairs) st.scan_ms += tm.ms(pr.first, pr.second);
+        st.total_ms = tm.ms(P.t0, P.t1);
     }
+    idx->stats = st;
+    return VROD_OK;
+}
+
+// begin = take the next slot and enqueue; end = complete the oldest slot (FIFO).
+static int search_begin(vrod_index* idx, const float* d_queries_raw, uint32_t nq, uint32_t k,
+                        uint64_t* d_out_ids, float* d_out_scores) {
+    if (idx->n_pending() >= 2) return fail(VROD_ERR_INVALID_ARG, "two searches are already pending: call vrod_search_end first");
+    Pending& P = idx->slot[idx->n_begun & 1];
+    int rc = search_enqueue(idx, P, d_queries_raw, nq, k, d_out_ids, d_out_scores);
+    if (rc != VROD_OK) {
+        // a half-enqueued search: drain the stream, consume the bad-value flag, leave the slot free
+        (void)hipStreamSynchronize(idx->stream);
+        (void)hipMemsetAsync(&idx->flags[0], 0, 4, idx->stream);
+        (void)hipStreamSynchronize(idx->stream);
+        return rc;
+    }
+    P.active = true;
+    idx->n_begun++;
+    return VROD_OK;
+}
+
+static int search_end(vrod_index* idx) {
+    if (idx->n_pending() == 0) return fail(VROD_ERR_INVALID_ARG, "no search is pending");
+    Pending& P = idx->slot[idx->n_ended & 1];
+    idx->n_ended++;
+    P.active = false;
+    return search_complete(idx, P);
+}
+
+static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, uint32_t k,
+                      uint64_t* d_out_ids, float* d_out_scores) {
+    VROD_TRY(search_begin(idx, d_queries_raw, nq, k, d_out_ids, d_out_scores));
+    return search_end(idx);
+}
+
+static int require_idle(const vrod_index* idx, const char* what) {
+    if (idx->n_pending()) return fail(VROD_ERR_INVALID_ARG, "%s while a search is pending: call vrod_search_end first", what);
+    return VROD_OK;
+}
+
+// The caller's stream holds the producers of the inputs and the last consumers of the output
+// buffers: order it before ours without stopping the host.
+static int order_after_caller(vrod_index* idx, void* stream) {
+    if (!idx->caller_ev) HIP_TRY(hipEventCreateWithFlags(&idx->caller_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(idx->caller_ev, (hipStream_t)stream));
+    HIP_TRY(hipStreamWaitEvent(idx->stream, idx->caller_ev, 0));
     return VROD_OK;
 }
 
@@ -582,12 +682,17 @@ int vrod_index_destroy(vrod_index* idx) {
     if (!idx) return VROD_OK;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    for (DevBuf* b : {&idx->raw_stage, &idx->nrm_ws, &idx->q_raw, &idx->q_f32, &idx->q_lp, &idx->scores, &idx->keys_a,
+    for (DevBuf* b : {&idx->raw_stage, &idx->nrm_ws, &idx->q_raw, &idx->q_lp, &idx->scores, &idx->keys_a,
                       &idx->keys_b, &idx->lists, &idx->small, &idx->hist, &idx->cand_rows, &idx->cand_fast, &idx->cand_canon,
                       &idx->out_ids, &idx->out_scores})
         b->release();
-    for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
-    if (idx->h_readback) (void)hipHostFree(idx->h_readback);
+    for (Pending& P : idx->slot) {
+        P.q_f32.release();
+        for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
+        if (P.done) (void)hipEventDestroy(P.done);
+        if (P.h_readback) (void)hipHostFree(P.h_readback);
+    }
+    if (idx->caller_ev) (void)hipEventDestroy(idx->caller_ev);
     if (idx->corpus) (void)hipFree(idx->corpus);
     if (idx->xnorm2) (void)hipFree(idx->xnorm2);
     if (idx->flags) (void)hipFree(idx->flags);
@@ -598,17 +703,20 @@ int vrod_index_destroy(vrod_index* idx) {
 
 int vrod_index_reserve(vrod_index* idx, uint64_t n_rows) {
     if (!idx) return fail(VROD_ERR_INVALID_ARG, "idx is null");
+    VROD_TRY(require_idle(idx, "vrod_index_reserve"));
     VROD_TRY(set_device(idx));
     return index_reserve(idx, n_rows);
 }
 
 int vrod_index_add(vrod_index* idx, const float* rows, uint64_t n) {
     if (!idx || (!rows && n)) return fail(VROD_ERR_INVALID_ARG, "null argument");
+    VROD_TRY(require_idle(idx, "vrod_index_add"));
     return index_add(idx, rows, n, false, 0, 0);
 }
 
 int vrod_index_add_synthetic(vrod_index* idx, uint64_t seed, uint64_t first_row, uint64_t n) {
     if (!idx) return fail(VROD_ERR_INVALID_ARG, "idx is null");
+    VROD_TRY(require_idle(idx, "vrod_index_add_synthetic"));
     return index_add(idx, nullptr, n, true, seed, first_row);
 }
 
@@ -628,6 +736,7 @@ int vrod_index_get_rows(vrod_index* idx, uint64_t first, uint64_t n, float* out_
     if (!idx || (!out_rows && n)) return fail(VROD_ERR_INVALID_ARG, "null argument");
     if (first + n > idx->count) return fail(VROD_ERR_INVALID_ARG, "rows [%llu, %llu) out of range", (unsigned long long)first, (unsigned long long)(first + n));
     if (!n) return VROD_OK;
+    VROD_TRY(require_idle(idx, "vrod_index_get_rows"));
     VROD_TRY(set_device(idx));
     VROD_TRY(idx->raw_stage.ensure(n * idx->dim * 4));
     launch_rows_get((const char*)idx->corpus + first * idx->row_bytes(), idx->dtype, n, idx->dim, idx->ld, idx->raw_stage.as<float>(), idx->stream);
@@ -647,16 +756,51 @@ static int check_search_args(vrod_index* idx, const void* q, uint32_t nq, uint32
 int vrod_search_device(vrod_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
                        uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, d_queries, nq, k, d_out_ids, d_out_scores));
+    VROD_TRY(require_idle(idx, "vrod_search_device"));
     VROD_TRY(set_device(idx));
-    if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // caller's inputs are ready
+    VROD_TRY(order_after_caller(idx, stream));   // the caller's inputs are ready
     return run_search(idx, d_queries, nq, k, d_out_ids, d_out_scores);
+}
+
+int vrod_search_begin_device(vrod_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
+                             uint64_t* d_out_ids, float* d_out_scores, void* stream) {
+    VROD_TRY(check_search_args(idx, d_queries, nq, k, d_out_ids, d_out_scores));
+    VROD_TRY(set_device(idx));
+    VROD_TRY(order_after_caller(idx, stream));
+    return search_begin(idx, d_queries, nq, k, d_out_ids, d_out_scores);
+}
+
+int vrod_search_begin_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t first_row, uint32_t nq,
+                                       uint32_t k, uint64_t* d_out_ids, float* d_out_scores, void* stream) {
+    VROD_TRY(check_search_args(idx, (void*)1, nq, k, d_out_ids, d_out_scores));
+    if (idx->n_pending() >= 2) return fail(VROD_ERR_INVALID_ARG, "two searches are already pending: call vrod_search_end first");
+    VROD_TRY(set_device(idx));
+    VROD_TRY(order_after_caller(idx, stream));
+    // the raw queries are consumed by the prepare launch of this same search: one shared buffer,
+    // stream-ordered (a regrowth frees it through hipFree, which waits for the device)
+    VROD_TRY(idx->q_raw.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
+    launch_synth_rows(seed, first_row, nq, idx->dim, idx->q_raw.as<float>(), idx->stream);
+    return search_begin(idx, idx->q_raw.as<float>(), nq, k, d_out_ids, d_out_scores);
+}
+
+int vrod_search_end(vrod_index* idx) {
+    if (!idx) return fail(VROD_ERR_INVALID_ARG, "idx is null");
+    VROD_TRY(set_device(idx));
+    return search_end(idx);
+}
+
+int vrod_search_pending(const vrod_index* idx, uint32_t* out_pending) {
+    if (!idx || !out_pending) return fail(VROD_ERR_INVALID_ARG, "null argument");
+    *out_pending = idx->n_pending();
+    return VROD_OK;
 }
 
 int vrod_search_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t first_row, uint32_t nq,
                                  uint32_t k, uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, (void*)1, nq, k, d_out_ids, d_out_scores));
+    VROD_TRY(require_idle(idx, "vrod_search_synthetic_device"));
     VROD_TRY(set_device(idx));
-    if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    VROD_TRY(order_after_caller(idx, stream));
     VROD_TRY(idx->q_raw.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
     launch_synth_rows(seed, first_row, nq, idx->dim, idx->q_raw.as<float>(), idx->stream);
     return run_search(idx, idx->q_raw.as<float>(), nq, k, d_out_ids, d_out_scores);
@@ -666,6 +810,7 @@ int vrod_search(vrod_index* idx, const float* queries, uint32_t nq, uint32_t k, 
                 float* out_scores) {
     VROD_TRY(check_search_args(idx, queries, nq, k, out_ids, out_scores));
     if (!nq) return VROD_OK;
+    VROD_TRY(require_idle(idx, "vrod_search"));
     VROD_TRY(set_device(idx));
     VROD_TRY(idx->q_raw.ensure((size_t)nq * idx->dim * 4));
     VROD_TRY(idx->out_ids.ensure((size_t)nq * k * 8));
@@ -709,6 +854,7 @@ int vrod_merge_topk_packed_device(int device, int metric, const void* d_packed, 
 
 int vrod_index_set_path(vrod_index* idx, int path) {
     if (!idx || path < VROD_PATH_AUTO || path > VROD_PATH_EXACT) return fail(VROD_ERR_INVALID_ARG, "bad path");
+    VROD_TRY(require_idle(idx, "vrod_index_set_path"));
     idx->path = path;
     return VROD_OK;
 }

@@ -139,6 +139,30 @@ class Index:
                                                    out_ids.data_ptr(), out_scores.data_ptr(), C.c_void_p(stream)))
         return out_ids, out_scores
 
+    # -- pipelined search: begin(s+1) before end(s) keeps the device busy between batches
+    def search_begin_device(self, d_queries, k: int, out_ids, out_scores):
+        import torch
+        assert d_queries.is_cuda and d_queries.dtype == torch.float32 and d_queries.is_contiguous()
+        stream = torch.cuda.current_stream(d_queries.device).cuda_stream
+        check(self._L.vrod_search_begin_device(self._h, d_queries.data_ptr(), d_queries.shape[0], int(k),
+                                               out_ids.data_ptr(), out_scores.data_ptr(), C.c_void_p(stream)))
+
+    def search_begin_synthetic_device(self, seed: int, first_row: int, nq: int, k: int, out_ids, out_scores):
+        import torch
+        stream = torch.cuda.current_stream(out_ids.device).cuda_stream
+        check(self._L.vrod_search_begin_synthetic_device(self._h, int(seed), int(first_row), int(nq), int(k),
+                                                         out_ids.data_ptr(), out_scores.data_ptr(), C.c_void_p(stream)))
+
+    def search_end(self):
+        """Complete the oldest pending search; its output tensors are final when this returns."""
+        check(self._L.vrod_search_end(self._h))
+
+    @property
+    def pending(self) -> int:
+        out = C.c_uint32()
+        check(self._L.vrod_search_pending(self._h, C.byref(out)))
+        return out.value
+
 
 def merge_topk_device(device: int, metric, ids, scores, out_ids=None, out_scores=None):
     """ids/scores: torch CUDA tensors [n_lists, nq, k] (int64 bits of uint64 / float32) -> merged [nq, k]."""
