@@ -1,0 +1,374 @@
+// Prototype (dev tool, not part of the library): 4-wave 256x256 bf16 tile, one wave per SIMD,
+// 128x128 per wave, persistent work-groups walking a strip of corpus tiles -- the structure
+// considered as the successor of scan_mfma_phased_kernel (8 waves, 128x64 per wave).
+// Epilogue: running max per (lane, query column) -- stands in for the threshold filter.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_w4 gemm_w4.hip && ./gemm_w4 [rows] [variant]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <type_traits>
+#include <utility>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GLDS16(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+#define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+constexpr int kStage = 65536;
+
+struct Args {
+    const char* corpus;   // [rows][ld] bf16
+    const char* queries;  // [1024][ld] bf16
+    float* out;           // [grid][256 threads][8] running maxima
+    uint32_t ld_bytes;
+    uint32_t ntiles;      // 256-row tiles
+    uint32_t nqb;
+    uint32_t flags;       // 1: A always from the strip's first tile (L2-hot), 2: no vmcnt wait (timing only)
+    unsigned long long* clk;  // [2]: shader-clock and 100 MHz wall-clock ticks of work-group 0
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// accumulator tile (m, n) of the wave's 8 x 8 grid of 16x16 tiles lives in a[(m*8+n)*4 .. +3]:
+// the AGPR file is owned by these statements, the compiler keeps the 256 arch VGPRs
+template <int BASE, bool ZERO>
+__device__ __forceinline__ void mfma1(const bf16x8& x, const bf16x8& y) {
+    if constexpr (ZERO)
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(x), "v"(y), "i"(BASE), "i"(BASE + 3) : "memory");
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(x), "v"(y), "i"(BASE), "i"(BASE + 3) : "memory");
+}
+template <int BASE, bool ZERO>
+__device__ __forceinline__ void mfma1_32(const bf16x8& x, const bf16x8& y) {
+    if constexpr (ZERO)
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(x), "v"(y), "i"(BASE), "i"(BASE + 15) : "memory");
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(x), "v"(y), "i"(BASE), "i"(BASE + 15) : "memory");
+}
+// 32x32x16 form (TIMING ONLY here: fragment layouts are not adapted): quadrant = 2 x 2 tiles x 4 k-steps,
+// group G = 2 MFMAs; fragment j of FA/FB = (tile j/4, k-step j%4)
+template <int MH, int NH, bool ZERO, int G>
+__device__ __forceinline__ void mfma_group32(const bf16x8 (&FA)[4][2], const bf16x8 (&FB)[4][2]) {
+    static_for<0, 2>([&](auto ic) {
+        constexpr int I = G * 2 + decltype(ic)::value;      // 0..15 = ks*4 + mt*2 + nt
+        constexpr int ks = I / 4, mt = (I / 2) % 2, nt = I % 2;
+        constexpr int ja = mt * 4 + ks, jb = nt * 4 + ks;
+        mfma1_32<(((MH * 2 + mt) * 4) + NH * 2 + nt) * 16, ZERO && ks == 0>(FA[ja >> 1][ja & 1], FB[jb >> 1][jb & 1]);
+    });
+}
+// group G (0..7) of a quadrant's 32 MFMAs: 4 MFMAs, index I = kk*16 + mm*4 + nn
+template <int MH, int NH, bool ZERO, int G, int VAR = 0>
+__device__ __forceinline__ void mfma_group(const bf16x8 (&FA)[4][2], const bf16x8 (&FB)[4][2]) {
+    if constexpr (VAR & 32) { mfma_group32<MH, NH, ZERO, G>(FA, FB); return; }
+    static_for<0, 4>([&](auto ic) {
+        constexpr int I = G * 4 + decltype(ic)::value;
+        constexpr int kk = I / 16, mm = (I / 4) % 4, nn = I % 4;
+        mfma1<((MH * 4 + mm) * 8 + NH * 4 + nn) * 4, ZERO && kk == 0>(FA[mm][kk], FB[nn][kk]);
+    });
+}
+template <int BASE>
+__device__ __forceinline__ f32x4 read_acc() {
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
+    return v;
+}
+
+// VAR bit 0: loads interleaved with the MFMA groups (else all loads of a phase first)
+template <int VAR>
+__global__ __launch_bounds__(256) void gemm_w4(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t slots = gridDim.x >> 3;
+    const uint32_t spx = slots / a.nqb;           // strips per XCD
+    const uint32_t qb = slot % a.nqb, strip = xcd * spx + slot / a.nqb, nstrips = 8 * spx;
+    if (slot >= spx * a.nqb) return;
+    const uint32_t t0 = (uint32_t)((uint64_t)a.ntiles * strip / nstrips);
+    const uint32_t t1 = (uint32_t)((uint64_t)a.ntiles * (strip + 1) / nstrips);
+    if (t0 >= t1) return;
+
+    const uint32_t KT = a.ld_bytes >> 7;
+    const uint32_t st_row = lane >> 3;
+    const uint32_t st_lane_off = st_row * a.ld_bytes + (((lane & 7) ^ st_row) << 4);
+    const uint32_t fr = lane & 15, fg = lane >> 4, r7 = fr & 7;
+    const uint32_t a_frag0 = ((wr * 16 + (fr >> 3)) << 10) + (r7 << 7);
+    const uint32_t b_frag0 = 32768u + ((wc * 16 + (fr >> 3)) << 10) + (r7 << 7);
+    const uint32_t c_off0 = ((0 * 4 + fg) ^ r7) << 4, c_off1 = ((1 * 4 + fg) ^ r7) << 4;
+
+    const char* q_base = a.queries + (uint64_t)qb * 256 * a.ld_bytes + st_lane_off;
+    const char* c_base = a.corpus + st_lane_off;
+    const uint32_t total_it = (t1 - t0) * KT;
+
+    float best[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) best[n] = -3.0e38f;
+    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+
+    // one DMA piece into buffer `buf` from the per-lane source pointers of the K-tile being
+    // staged: i in 0..7 = A pieces, 8..15 = B pieces of this wave (piece stride 8 rows)
+    const uint64_t piece_stride = 8ull * a.ld_bytes;
+    const char* a_src = c_base + ((uint64_t)t0 * 256 + wave * 64) * a.ld_bytes;   // K-tile being staged
+    const char* b_src = q_base + (uint64_t)wave * 64 * a.ld_bytes;
+    uint32_t st_kt = 0, st_tile = t0;
+    auto stage1 = [&](uint32_t buf, int i) {
+        if constexpr (VAR & 4) { if (buf > 1) return; }
+        char* l = lds + (buf & 1) * kStage;
+        const uint32_t p = wave * 8 + (i & 7);
+        if (i < 8) GLDS16(a_src + (uint64_t)(i & 7) * piece_stride, l + p * 1024);
+        else GLDS16(b_src + (uint64_t)(i & 7) * piece_stride, l + 32768 + p * 1024);
+    };
+    // unit-wise staging (VAR bit 4): unit A_mh / B_nh = the 16 pieces of rows [h*64, h*64+64) of both
+    // 128-row halves; this wave moves 4 of them: idx = wave*4 + i -> piece (idx>>3)*16 + (idx&7) + h*8
+    const char* ua_src = c_base + (uint64_t)t0 * 256 * a.ld_bytes;
+    const char* ub_src = q_base;
+    auto stage_unit = [&](uint32_t buf, bool is_b, int h, int i) {
+        const uint32_t idx = wave * 4 + i;
+        const uint32_t p = (idx >> 3) * 16 + (idx & 7) + h * 8;
+        char* l = lds + (buf & 1) * kStage + (is_b ? 32768 : 0) + p * 1024;
+        GLDS16((is_b ? ub_src : ua_src) + (uint64_t)p * piece_stride, l);
+    };
+    // advance the staging pointers by one K-tile (clamped at the end of the strip: the last
+    // K-tile is re-staged, never read)
+    auto stage_advance = [&]() {
+        if (st_kt + 1 < KT) { ++st_kt; a_src += 128; b_src += 128; ua_src += 128; ub_src += 128; }
+        else if (st_tile + 1 < t1) { st_kt = 0; ++st_tile; a_src += ((a.flags & 1) ? 0ull : 256ull * a.ld_bytes) - (uint64_t)(KT - 1) * 128; b_src -= (uint64_t)(KT - 1) * 128;
+                                       ua_src += ((a.flags & 1) ? 0ull : 256ull * a.ld_bytes) - (uint64_t)(KT - 1) * 128; ub_src -= (uint64_t)(KT - 1) * 128; }
+    };
+
+    for (int i = 0; i < 16; ++i) stage1(0, i);
+    stage_advance();
+    for (int i = 0; i < 16; ++i) stage1(1, i);
+    stage_advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16x8 FA0[4][2], FA1[4][2], FBx[4][2], FBy[4][2];
+
+#define LOAD_A1(FA, MH, L, J) if (!(VAR & 8) || it == 0) FA[(J) >> 1][(J) & 1] = *reinterpret_cast<const bf16x8*>((L) + a_frag0 + ((MH) * 4 + ((J) >> 1)) * 2048 + (((J) & 1) ? c_off1 : c_off0));
+#define LOAD_B1(FB, NH, L, J) if (!(VAR & 8) || it == 0) FB[(J) >> 1][(J) & 1] = *reinterpret_cast<const bf16x8*>((L) + b_frag0 + ((NH) * 4 + ((J) >> 1)) * 2048 + (((J) & 1) ? c_off1 : c_off0));
+// one phase: 8 groups of 4 MFMAs on quadrant (MH, NH) with the loads LD(j) and DMA pieces DM(j) between them
+#define PHASE_Z(FA, FB, MH, NH, ZERO, LD, DM)                                                      \
+    if constexpr (!(VAR & 1)) { LD(0) LD(1) LD(2) LD(3) LD(4) LD(5) LD(6) LD(7) DM(0) DM(1) DM(2) DM(3) DM(4) DM(5) DM(6) DM(7) } \
+    mfma_group<MH, NH, ZERO, 0, VAR>(FA, FB); if constexpr (VAR & 1) { LD(0) DM(0) }                    \
+    mfma_group<MH, NH, ZERO, 1, VAR>(FA, FB); if constexpr (VAR & 1) { LD(1) DM(1) }                    \
+    mfma_group<MH, NH, ZERO, 2, VAR>(FA, FB); if constexpr (VAR & 1) { LD(2) DM(2) }                    \
+    mfma_group<MH, NH, ZERO, 3, VAR>(FA, FB); if constexpr (VAR & 1) { LD(3) DM(3) }                    \
+    mfma_group<MH, NH, ZERO, 4, VAR>(FA, FB); if constexpr (VAR & 1) { LD(4) DM(4) }                    \
+    mfma_group<MH, NH, ZERO, 5, VAR>(FA, FB); if constexpr (VAR & 1) { LD(5) DM(5) }                    \
+    mfma_group<MH, NH, ZERO, 6, VAR>(FA, FB); if constexpr (VAR & 1) { LD(6) DM(6) }                    \
+    mfma_group<MH, NH, ZERO, 7, VAR>(FA, FB); if constexpr (VAR & 1) { LD(7) DM(7) }
+#define PHASE(FA, FB, MH, NH, LD, DM)                                                              \
+    if (first) { PHASE_Z(FA, FB, MH, NH, true, LD, DM) } else { PHASE_Z(FA, FB, MH, NH, false, LD, DM) }
+#define NOP(j)
+
+#define ITER(BX, BY)                                                                               \
+    {                                                                                              \
+        const char* l = lds + (it & 1) * kStage;                                                   \
+        const char* ln = lds + ((it + 1) & 1) * kStage;                                            \
+        const bool first = (it % KT) == 0;                                                         \
+        _Pragma("push_macro(\"LDQ\")")                                                             \
+        /* q0: (0,0), reads B1 of this K-tile */                                                   \
+        PHASE(FA0, BX, 0, 0, LDQ0, NOP)                                                            \
+        /* q1: (0,1), reads A1 */                                                                  \
+        PHASE(FA0, BY, 0, 1, LDQ1, NOP)                                                            \
+        if (!(a.flags & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
+        BARRIER();                                                                                 \
+        /* q2: (1,1): next stage readable (A0'), this stage's buffer refillable */                 \
+        PHASE(FA1, BY, 1, 1, LDQ2, DMQ2)                                                           \
+        /* q3: (1,0): B0' into BY */                                                               \
+        PHASE(FA1, BX, 1, 0, LDQ3, DMQ3)                                                           \
+        stage_advance();                                                                           \
+        if (!(VAR & 2) && (it % KT) == KT - 1) {                                                   \
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                     \
+            static_for<0, 64>([&](auto ic) {                                                       \
+                constexpr int m = decltype(ic)::value / 8, n = decltype(ic)::value % 8;            \
+                const f32x4 v = read_acc<(m * 8 + n) * 4>();                                       \
+                best[n] = fmaxf(best[n], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));             \
+            });                                                                                    \
+        }                                                                                          \
+        ++it;                                                                                      \
+    }
+
+// spread variant: 4 DMA pieces per phase, two barriers per K-tile, K-tile it+2 staged during iteration it
+#define PHASE_S(FA, FB, MH, NH, ZERO, LD, DM)                                                      \
+    mfma_group<MH, NH, ZERO, 0, VAR>(FA, FB); LD(0) LD(1) DM(0)                                         \
+    mfma_group<MH, NH, ZERO, 1, VAR>(FA, FB); LD(2) LD(3)                                               \
+    mfma_group<MH, NH, ZERO, 2, VAR>(FA, FB); LD(4) LD(5) DM(1)                                         \
+    mfma_group<MH, NH, ZERO, 3, VAR>(FA, FB); LD(6) LD(7)                                               \
+    mfma_group<MH, NH, ZERO, 4, VAR>(FA, FB); DM(2)                                                     \
+    mfma_group<MH, NH, ZERO, 5, VAR>(FA, FB);                                                           \
+    mfma_group<MH, NH, ZERO, 6, VAR>(FA, FB); DM(3)                                                     \
+    mfma_group<MH, NH, ZERO, 7, VAR>(FA, FB);
+#define PHASE2(FA, FB, MH, NH, LD, DM)                                                             \
+    if (first) { PHASE_S(FA, FB, MH, NH, true, LD, DM) } else { PHASE_S(FA, FB, MH, NH, false, LD, DM) }
+#define ITER2(BX, BY)                                                                              \
+    {                                                                                              \
+        const char* l = lds + (it & 1) * kStage;                                                   \
+        const char* ln = lds + ((it + 1) & 1) * kStage;                                            \
+        const bool first = (it % KT) == 0;                                                         \
+        PHASE2(FA0, BX, 0, 0, LDQ0, DMU0)                                                          \
+        PHASE2(FA0, BY, 0, 1, LDQ1, DMU1)                                                          \
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                               \
+        BARRIER();                                                                                 \
+        PHASE2(FA1, BY, 1, 1, LDQ2, DMU2)                                                          \
+        PHASE2(FA1, BX, 1, 0, LDQ3, DMU3)                                                          \
+        stage_advance();                                                                           \
+        if (!(VAR & 2) && (it % KT) == KT - 1) {                                                   \
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                     \
+            static_for<0, 64>([&](auto ic) {                                                       \
+                constexpr int m = decltype(ic)::value / 8, n = decltype(ic)::value % 8;            \
+                const f32x4 v = read_acc<(m * 8 + n) * 4>();                                       \
+                best[n] = fmaxf(best[n], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));             \
+            });                                                                                    \
+        }                                                                                          \
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                               \
+        BARRIER();                                                                                 \
+        ++it;                                                                                      \
+    }
+#define DMU0(j) stage_unit(it & 1, false, 0, j);
+#define DMU1(j) stage_unit(it & 1, true, 0, j);
+#define DMU2(j) stage_unit(it & 1, true, 1, j);
+#define DMU3(j) stage_unit(it & 1, false, 1, j);
+
+    // frags of K-tile 0
+    uint32_t it = 0;
+#define LDP_A(j) LOAD_A1(FA0, 0, lds, j)
+#define LDP_B(j) LOAD_B1(FBx, 0, lds, j)
+    LDP_A(0) LDP_A(1) LDP_A(2) LDP_A(3) LDP_A(4) LDP_A(5) LDP_A(6) LDP_A(7)
+    LDP_B(0) LDP_B(1) LDP_B(2) LDP_B(3) LDP_B(4) LDP_B(5) LDP_B(6) LDP_B(7)
+    if constexpr (VAR & 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); BARRIER(); }
+    while (it < total_it) {          // total_it is even (KT even)
+#define LDQ0(j) LOAD_B1(FBy, 1, l, j)
+#define LDQ1(j) LOAD_A1(FA1, 1, l, j)
+#define LDQ2(j) LOAD_A1(FA0, 0, ln, j)
+#define LDQ3(j) LOAD_B1(FBy, 0, ln, j)
+#define DMQ2(j) stage1((it & 1) + ((VAR & 4) ? 2 : 0), j);
+#define DMQ3(j) stage1((it & 1) + ((VAR & 4) ? 2 : 0), 8 + j);
+        if constexpr (VAR & 16) ITER2(FBx, FBy) else ITER(FBx, FBy)
+#undef LDQ0
+#undef LDQ3
+#define LDQ0(j) LOAD_B1(FBx, 1, l, j)
+#define LDQ3(j) LOAD_B1(FBx, 0, ln, j)
+        if constexpr (VAR & 16) ITER2(FBy, FBx) else ITER(FBy, FBx)
+#undef LDQ0
+#undef LDQ3
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64() - clk0; a.clk[1] = wall_clock64() - wall0; }
+    float* o = a.out + ((uint64_t)blockIdx.x * 256 + tid) * 8;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) o[n] = best[n];
+}
+
+__global__ void fill_kernel(uint16_t* p, uint64_t n, uint64_t seed) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t z = (i + seed * 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        const float v = ((int)(z & 0xFFFF) - 32768) * (0.06f / 32768.f);
+        p[i] = (uint16_t)(__float_as_uint(v) >> 16);
+    }
+}
+
+// reference: max over rows of dot(q, x) for a sample of queries
+__global__ void ref_kernel(const uint16_t* c, const uint16_t* q, uint32_t rows, uint32_t ld, uint32_t dim, const uint32_t* qsel, float* out) {
+    const uint32_t qi = qsel[blockIdx.y];
+    float best = -3.0e38f;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (uint32_t k = 0; k < dim; ++k)
+            s += __uint_as_float((uint32_t)c[(uint64_t)r * ld + k] << 16) * __uint_as_float((uint32_t)q[(uint64_t)qi * ld + k] << 16);
+        best = fmaxf(best, s);
+    }
+    atomicMax((int*)&out[blockIdx.y], __float_as_int(best < 0.f ? 0.f : best));   // positive maxima only
+}
+
+template <int VAR> static double run(const Args& a, int reps) {
+    hipFuncSetAttribute((const void*)gemm_w4<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    gemm_w4<VAR><<<256, 256, 2 * kStage>>>(a);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) gemm_w4<VAR><<<256, 256, 2 * kStage>>>(a);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) printf("HIP error: %s\n", hipGetErrorString(e));
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t rows = argc > 1 ? atoi(argv[1]) : 1048576, dim = 768, ld = 768, nq = 1024;
+    const int var = argc > 2 ? atoi(argv[2]) : 0;
+    uint16_t *d_c, *d_q; float* d_out;
+    hipMalloc(&d_c, (size_t)rows * ld * 2); hipMalloc(&d_q, (size_t)nq * ld * 2); hipMalloc(&d_out, 256 * 256 * 8 * 4);
+    fill_kernel<<<4096, 256>>>(d_c, (uint64_t)rows * ld, 1);
+    fill_kernel<<<256, 256>>>(d_q, (uint64_t)nq * ld, 2);
+    hipMemset(d_out, 0, 256 * 256 * 8 * 4);
+    const uint32_t flags = argc > 3 ? atoi(argv[3]) : 0;
+    unsigned long long* d_clk; hipMalloc(&d_clk, 16);
+    Args a{(const char*)d_c, (const char*)d_q, d_out, ld * 2, rows / 256, nq / 256, flags, d_clk};
+    double ms = 0;
+    switch (var) {
+        case 0: ms = run<0>(a, 5); break;
+        case 1: ms = run<1>(a, 5); break;
+        case 3: ms = run<3>(a, 5); break;     // no epilogue (timing only)
+        case 5: ms = run<5>(a, 5); break;     // no DMA in the loop (timing only)
+        case 7: ms = run<7>(a, 5); break;     // neither
+        case 9: ms = run<9>(a, 5); break;     // no fragment reads in the loop (timing only)
+        case 15: ms = run<15>(a, 5); break;   // MFMA only
+        case 17: ms = run<17>(a, 5); break;   // spread DMA, two barriers per K-tile
+        case 19: ms = run<19>(a, 5); break;   // same without the epilogue (timing only)
+        case 49: ms = run<49>(a, 5); break;   // 17 with 32x32x16 MFMAs (timing only)
+        case 51: ms = run<51>(a, 5); break;   // 19 with 32x32x16 MFMAs (timing only)
+        case 47: ms = run<47>(a, 5); break;   // 15 (MFMA only) with 32x32x16 MFMAs
+        case 33: ms = run<33>(a, 5); break;   // 1 with 32x32x16
+        default: printf("bad variant\n"); return 1;
+    }
+    const double tf = 2.0 * rows * nq * dim / (ms * 1e-3) / 1e12;
+    unsigned long long hclk[2]; hipMemcpy(hclk, d_clk, 16, hipMemcpyDeviceToHost);
+    const double ghz = (double)hclk[0] / (double)hclk[1] * 0.1;
+    printf("variant %2d flags %u rows %u: %.3f ms  %7.1f TFLOP/s  sclk %.2f GHz  -> %.1f %% of the MFMA rate at that clock\n", var, flags, rows, ms, tf, ghz,
+           100.0 * tf / (2500.0 * ghz / 2.4));
+    if ((var & ~17) || flags) return 0;   // timing-only variants compute garbage on purpose
+
+    // validate 16 sampled queries against the reference
+    std::vector<float> h(256 * 256 * 8);
+    hipMemcpy(h.data(), d_out, h.size() * 4, hipMemcpyDeviceToHost);
+    std::vector<float> qmax(nq, -3.0e38f);
+    for (uint32_t b = 0; b < 256; ++b) {
+        const uint32_t slot = b >> 3, qb = slot % 4;
+        for (uint32_t t = 0; t < 256; ++t) {
+            const uint32_t lane = t & 63, wave = t >> 6, wc = wave & 1, fr = lane & 15;
+            for (int n = 0; n < 8; ++n) {
+                const uint32_t q = qb * 256 + wc * 128 + n * 16 + fr;
+                qmax[q] = fmaxf(qmax[q], h[((size_t)b * 256 + t) * 8 + n]);
+            }
+        }
+    }
+    uint32_t hsel[16]; for (int i = 0; i < 16; ++i) hsel[i] = (i * 67 + 5) % nq;
+    uint32_t* d_sel; float* d_ref; hipMalloc(&d_sel, 64); hipMalloc(&d_ref, 64);
+    hipMemcpy(d_sel, hsel, 64, hipMemcpyHostToDevice); hipMemset(d_ref, 0, 64);
+    ref_kernel<<<dim3(512, 16), 256>>>(d_c, d_q, rows, ld, dim, d_sel, d_ref);
+    float href[16]; hipMemcpy(href, d_ref, 64, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 16; ++i) {
+        const float g = qmax[hsel[i]];
+        if (fabsf(g - href[i]) > 1e-4f * fmaxf(1.f, fabsf(href[i]))) { ++bad; printf("  q%u: got %g ref %g\n", hsel[i], g, href[i]); }
+    }
+    printf("validation: %s\n", bad ? "MISMATCH" : "ok");
+    return bad ? 2 : 0;
+}

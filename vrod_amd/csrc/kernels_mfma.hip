@@ -36,6 +36,7 @@
 // Roofline: MFMA.  Algorithmic flops per launch = 2 * nq * rows * dim  (SURVEY.md 8d).
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "vrod_common.h"
 #include "vrod_kernels.h"
@@ -51,6 +52,13 @@ constexpr int kLogCap = 2048;                     // LDS log entries (8 B each)
 constexpr int kLdsLog = 2 * kStageBytes;          // byte offset of the log
 constexpr int kLdsCtl = kLdsLog + kLogCap * 8;    // [0] log count, [1..2] flush flags
 constexpr int kLdsTotal = kLdsCtl + 64;
+// 4-wave kernel only: the work-group's 256 thresholds / query norms and two 256-row slots of row
+// norms live in LDS, so that the tile epilogue issues no global load (a compiler-counted load
+// there would drain the LDS-DMA pieces in flight)
+constexpr int kLdsThr = kLdsTotal;                // [256] f32
+constexpr int kLdsQn2 = kLdsThr + 1024;           // [256] f32
+constexpr int kLdsXn2 = kLdsQn2 + 1024;           // [2][256] f32, slot = tile parity
+constexpr int kLdsTotalW4 = kLdsXn2 + 2048;
 
 // raw s_barrier (no vmcnt drain) fenced for the compiler only: memory operations may not be
 // moved across it, nothing is emitted for the fences
@@ -124,7 +132,7 @@ __device__ __forceinline__ void flush_log(const MfmaKernelArgs& a, uint2* log, u
                                           uint32_t rel_base, int tid) {
     __syncthreads();
     const uint32_t n = log_cnt[0] < (uint32_t)kLogCap ? log_cnt[0] : (uint32_t)kLogCap;
-    for (uint32_t i = tid; i < n; i += 512) {
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
         const uint2 e = log[i];
         global_append(a, qb * kBN + (e.y >> 24), e.x, rel_base + (e.y & 0xFFFFFFu));
     }
@@ -597,6 +605,361 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Schedule 3 (bf16 default): 4 waves, one per SIMD, 128 rows x 128 queries per wave.
+//
+// Why: with 8 waves every K-tile moves 192 KB of fragment reads through the LDS and needs 8
+// barriers; with 4 waves it is 128 KB and 2 barriers, and the per-lane filter state is 8
+// thresholds instead of 4 per wave but half as many waves.  One wave per SIMD owns the whole
+// 512-entry register file: the 256 accumulator registers are a[0:255], named literally by the
+// inline-asm MFMAs (hipcc's own allocation of a 256-register accumulator array spills; the
+// clobber list below makes the kernel descriptor allocate the AGPRs and keeps the compiler out
+// of them -- audited in the build: no compiler v_accvgpr_* and no scratch, scripts/audit_w4.py).
+// Tile (m, n) of the wave's 8 x 8 grid of 16x16 tiles is a[(m*8+n)*4 .. +3].
+//
+// Per K-tile, 4 phases over the accumulator quadrants (mh, nh) = (0,0) (0,1) (1,1) (1,0), 32 MFMAs
+// each, with between them the 8 fragment reads the NEXT phase needs and 4 LDS-DMA pieces:
+//   q0: MFMA(A0,B0) | read B1 of this K-tile        | stage A_m0 of K-tile it+2
+//   q1: MFMA(A0,B1) | read A1                       | stage B_n0 of K-tile it+2
+//   -- wait vmcnt(16) (A_m0, B_n0 of K-tile it+1 have landed), barrier M
+//   q2: MFMA(A1,B1) | read A0 of K-tile it+1        | stage B_n1 of K-tile it+2
+//   q3: MFMA(A1,B0) | read B0 of K-tile it+1        | stage A_m1 of K-tile it+2
+//   -- tile epilogue (filter / dense store) when the K-tile was the tile's last
+//   -- wait vmcnt(16) (B_n1, A_m1 of K-tile it+1 have landed), barrier E
+// K-tile it+2 goes into the buffer of K-tile it: a unit is restaged only after the barrier that
+// follows its last read (A_m0, B_n0: read in q2, q3 of iteration it-1, barrier E(it-1); B_n1,
+// A_m1: read in q0, q1, barrier M(it)), every ds_read is retired (lgkmcnt(0)) before the barrier,
+// and a unit is read only after every wave's counted wait for it plus a barrier.  16 to 32 DMA
+// pieces per wave stay in flight: a piece has more than one K-tile of MFMAs to land.
+// The first K-tile of a corpus tile uses the C = 0 form of the MFMA, so the accumulators are
+// never cleared; the epilogue reads them with v_accvgpr_read.
+// ---------------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// The accumulator file is owned by these statements: tile (m, n) is a[(m*8+n)*4 .. +3], named
+// literally.  (Letting hipcc allocate the 256 accumulator registers -- a plain f32x4 array with
+// the MFMA builtin, or "a"-constrained asm operands -- ends in hundreds of spills.)  This is sound
+// only while the compiler keeps out of the AGPRs wherever the accumulators are live, which
+// scripts/audit_w4.py checks on the emitted assembly (tests/test_build_audit.py runs it).
+template <int BASE, bool ZERO>
+__device__ __forceinline__ void w4_mfma1(const bf16x8& x, const bf16x8& y) {
+    if constexpr (ZERO)
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(x), "v"(y), "i"(BASE), "i"(BASE + 3) : "memory");
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(x), "v"(y), "i"(BASE), "i"(BASE + 3) : "memory");
+}
+// group G (0..7) of a quadrant's 32 MFMAs: index I = kk*16 + mm*4 + nn
+template <int MH, int NH, bool ZERO, int G>
+__device__ __forceinline__ void w4_mfma_group(const bf16x8 (&FA)[4][2], const bf16x8 (&FB)[4][2]) {
+    static_for<0, 4>([&](auto ic) {
+        constexpr int I = G * 4 + decltype(ic)::value;
+        constexpr int kk = I / 16, mm = (I / 4) % 4, nn = I % 4;
+        w4_mfma1<((MH * 4 + mm) * 8 + NH * 4 + nn) * 4, ZERO && kk == 0>(FA[mm][kk], FB[nn][kk]);
+    });
+}
+template <int BASE>
+__device__ __forceinline__ f32x4 w4_read_acc() {
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
+    return v;
+}
+
+// The fused filter of the 4-wave kernel: the wave's 128 x 128 scores (in a[0:255]) against the 8
+// per-lane thresholds.  row_w = first row of the lane's 4-row group in tile m = 0.
+template <int METRIC>
+__device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const float* thr_l, const float* qn2_l, const float* xn_l,
+                                               uint32_t row_w, uint32_t ql0, uint32_t qb, uint32_t rel_base,
+                                               uint2* log, uint32_t* log_cnt) {
+    // thr_l / qn2_l: the work-group's per-query values in LDS; xn_l: this lane's 4-row group of the
+    // tile's row norms in LDS (m = 0), 16 floats apart per m
+    float thr[8], qn2[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        thr[n] = thr_l[ql0 + n * 16];
+        qn2[n] = METRIC == M_L2 ? qn2_l[ql0 + n * 16] : 0.0f;
+    }
+    const uint32_t lds_log_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log;
+    const uint32_t lds_cnt_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log_cnt;
+    // the last MFMAs are still in the pipe: an accumulator may be read 4 passes + 2 states later
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    float best[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) best[n] = worst_score(METRIC);
+    static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (METRIC == M_L2) xv = *reinterpret_cast<const f32x4*>(xn_l + m * 16);
+        static_for<0, 8>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            const f32x4 v = w4_read_acc<(m * 8 + n) * 4>();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2[n]);
+                best[n] = METRIC == M_COSINE ? __builtin_fmaxf(best[n], sc) : __builtin_fminf(best[n], sc);
+            }
+        });
+    });
+    bool hit[8];
+    bool any = false;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        hit[n] = better<METRIC>(best[n], thr[n]);
+        any |= hit[n];
+    }
+    if (__any(any)) {
+        static_for<0, 8>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            if (!__any(hit[n])) return;
+            const uint32_t ql = ql0 + n * 16;
+            static_for<0, 8>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (METRIC == M_L2) xv = *reinterpret_cast<const f32x4*>(xn_l + m * 16);
+                const f32x4 v = w4_read_acc<(m * 8 + n) * 4>();
+                float sc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[r] = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2[n]);
+                const float tb = METRIC == M_COSINE ? __builtin_fmaxf(__builtin_fmaxf(sc[0], sc[1]), __builtin_fmaxf(sc[2], sc[3]))
+                                                    : __builtin_fminf(__builtin_fminf(sc[0], sc[1]), __builtin_fminf(sc[2], sc[3]));
+                if (!__any(better<METRIC>(tb, thr[n]))) return;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t row = row_w + m * 16 + r;
+                    if (better<METRIC>(sc[r], thr[n]) && row >= a.row_lo && row < a.row_end) {
+                        uint32_t pos;   // LDS log append in asm (see filter_tile)
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=v"(pos) : "v"(lds_cnt_addr), "v"(1u) : "memory");
+                        if (pos < (uint32_t)kLogCap) {
+                            const uint64_t e = ((uint64_t)((ql << 24) | (row - rel_base)) << 32) | __float_as_uint(sc[r]);
+                            asm volatile("ds_write_b64 %0, %1" :: "v"(lds_log_addr + pos * 8u), "v"(e) : "memory");
+                            if (pos >= (uint32_t)(kLogCap / 2))
+                                asm volatile("ds_write_b32 %0, %1" :: "v"(lds_cnt_addr + 12u), "v"(1u) : "memory");
+                        } else {
+                            global_append(a, qb * kBN + ql, __float_as_uint(sc[r]), row);
+                        }
+                    }
+                }
+            });
+        });
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int METRIC>
+__device__ __forceinline__ void w4_dense_store_tile(const MfmaKernelArgs& a, const float* qn2_l, uint32_t ql0, uint32_t row_w, uint32_t gq0) {
+    float qn2[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) qn2[n] = METRIC == M_L2 ? qn2_l[ql0 + n * 16] : 0.0f;
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const uint32_t row = row_w + m * 16;
+        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (METRIC == M_L2) xv = *reinterpret_cast<const f32x4*>(a.xnorm2 + row);
+        const bool in = row - a.row_lo < a.dense_ld;
+        static_for<0, 8>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            const f32x4 v = w4_read_acc<(m * 8 + n) * 4>();
+            f32x4 sc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2[n]);
+            if (in) *reinterpret_cast<f32x4*>(a.dense_out + (uint64_t)(gq0 + n * 16) * a.dense_ld + (row - a.row_lo)) = sc;
+        });
+    });
+}
+
+template <int METRIC, bool DENSE>
+__global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // makes the kernel descriptor allocate a[0:255]
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+    uint32_t* log_cnt = reinterpret_cast<uint32_t*>(lds + kLdsCtl);  // [0] count [3] flush due
+    uint2* log = reinterpret_cast<uint2*>(lds + kLdsLog);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    uint32_t strip, qb0, qb_step;
+    if (!wg_assignment(a, strip, qb0, qb_step)) return;
+    const uint32_t t0 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * strip / a.nstrips);
+    const uint32_t t1 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * (strip + 1) / a.nstrips);
+    if (t0 >= t1) return;
+
+    if (tid == 0) { log_cnt[0] = 0; log_cnt[1] = 0; log_cnt[2] = 0; log_cnt[3] = 0; }
+    __syncthreads();
+
+    const uint32_t KT = a.ld_bytes >> 7;
+    const uint32_t rel_base = a.tile_first * kBM;
+    const uint32_t st_row = lane >> 3;
+    const uint32_t st_lane_off = st_row * a.ld_bytes + (((lane & 7) ^ st_row) << 4);
+    const uint32_t fr = lane & 15, fg = lane >> 4, r7 = fr & 7;
+    const uint32_t a_frag0 = ((wr * 16 + (fr >> 3)) << 10) + (r7 << 7);
+    const uint32_t b_frag0 = 32768u + ((wc * 16 + (fr >> 3)) << 10) + (r7 << 7);
+    const uint32_t c_off0 = ((0 * 4 + fg) ^ r7) << 4, c_off1 = ((1 * 4 + fg) ^ r7) << 4;
+    const uint64_t piece_stride = 8ull * a.ld_bytes;
+    const uint32_t total_it = (t1 - t0) * KT;
+
+    for (uint32_t qb = qb0; qb < a.nqb; qb += qb_step) {
+        float* thr_l = reinterpret_cast<float*>(lds + kLdsThr);
+        float* qn2_l = reinterpret_cast<float*>(lds + kLdsQn2);
+        const float* xn_l = reinterpret_cast<const float*>(lds + kLdsXn2);
+        thr_l[tid] = DENSE ? 0.0f : a.thr[qb * kBN + tid];
+        qn2_l[tid] = METRIC == M_L2 ? a.qnorm2[qb * kBN + tid] : 0.0f;
+        // (published by the prologue's __syncthreads)
+        // per-lane source pointers of the K-tile being staged (two K-tiles ahead of the MFMAs)
+        const char* ua_src = a.corpus + st_lane_off + (uint64_t)t0 * kBM * a.ld_bytes;
+        const char* ub_src = a.queries + st_lane_off + (uint64_t)qb * kBN * a.ld_bytes;
+        uint32_t st_kt = 0, st_tile = t0;
+        // unit A_mh / B_nh = the 16 pieces (8 rows x 128 B each) of rows [h*64, h*64+64) of both
+        // 128-row halves; this wave moves 4 of them: idx = wave*4 + i -> piece (idx>>3)*16 + (idx&7) + h*8
+        auto stage_unit = [&](uint32_t buf, bool is_b, int h, int i) {
+            const uint32_t idx = wave * 4 + i;
+            const uint32_t p = (idx >> 3) * 16 + (idx & 7) + h * 8;
+            char* l = lds + (buf & 1) * kStageBytes + (is_b ? 32768 : 0) + p * 1024;
+            VROD_GLDS16((is_b ? ub_src : ua_src) + (uint64_t)p * piece_stride, l);
+        };
+        // next K-tile of the strip (clamped at its end: the last K-tile is re-staged, never read)
+        auto stage_advance = [&]() {
+            if (st_kt + 1 < KT) { ++st_kt; ua_src += 128; ub_src += 128; }
+            else if (st_tile + 1 < t1) {
+                st_kt = 0; ++st_tile;
+                ua_src += (uint64_t)kBM * a.ld_bytes - (uint64_t)(KT - 1) * 128;
+                ub_src -= (uint64_t)(KT - 1) * 128;
+            }
+        };
+
+        // ---- prologue: K-tiles 0 and 1 whole, landed; fragments A0, B0 of K-tile 0
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage_unit(0, u == 1 || u == 2, u >> 1, i);
+        stage_advance();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage_unit(1, u == 1 || u == 2, u >> 1, i);
+        stage_advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        bf16x8 FA0[4][2], FA1[4][2], FBx[4][2], FBy[4][2];
+#define W4_LOAD_A1(FA, MH, L, J) FA[(J) >> 1][(J) & 1] = *reinterpret_cast<const bf16x8*>((L) + a_frag0 + ((MH) * 4 + ((J) >> 1)) * 2048 + (((J) & 1) ? c_off1 : c_off0));
+#define W4_LOAD_B1(FB, NH, L, J) FB[(J) >> 1][(J) & 1] = *reinterpret_cast<const bf16x8*>((L) + b_frag0 + ((NH) * 4 + ((J) >> 1)) * 2048 + (((J) & 1) ? c_off1 : c_off0));
+#define W4_PHASE_S(FA, FB, MH, NH, ZERO, LD, DM)                                                   \
+    w4_mfma_group<MH, NH, ZERO, 0>(FA, FB); LD(0) LD(1) DM(0)                                      \
+    w4_mfma_group<MH, NH, ZERO, 1>(FA, FB); LD(2) LD(3)                                            \
+    w4_mfma_group<MH, NH, ZERO, 2>(FA, FB); LD(4) LD(5) DM(1)                                      \
+    w4_mfma_group<MH, NH, ZERO, 3>(FA, FB); LD(6) LD(7)                                            \
+    w4_mfma_group<MH, NH, ZERO, 4>(FA, FB); DM(2)                                                  \
+    w4_mfma_group<MH, NH, ZERO, 5>(FA, FB);                                                        \
+    w4_mfma_group<MH, NH, ZERO, 6>(FA, FB); DM(3)                                                  \
+    w4_mfma_group<MH, NH, ZERO, 7>(FA, FB);
+#define W4_PHASE(FA, FB, MH, NH, LD, DM)                                                           \
+    if (first) { W4_PHASE_S(FA, FB, MH, NH, true, LD, DM) } else { W4_PHASE_S(FA, FB, MH, NH, false, LD, DM) }
+#define W4_DMU0(j) stage_unit(it & 1, false, 0, j);
+#define W4_DMU1(j) stage_unit(it & 1, true, 0, j);
+#define W4_DMU2(j) stage_unit(it & 1, true, 1, j);
+#define W4_DMU3(j) stage_unit(it & 1, false, 1, j);
+#define W4_ITER(BX, BY, LDQ0, LDQ3)                                                                \
+    {                                                                                              \
+        const char* l = lds + (it & 1) * kStageBytes;                                              \
+        const char* ln = lds + ((it + 1) & 1) * kStageBytes;                                       \
+        const bool first = kt == 0;                                                                \
+        /* pacing of the sibling work-groups (see the phased kernel) */                            \
+        if (a.pace_every && first && it > 0 && tid == 0) {                                         \
+            const uint32_t tix = tile - t0;                                                        \
+            if (tix % a.pace_every == 0) {                                                         \
+                uint32_t* ctr = a.pace + strip;                                                    \
+                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       \
+                const uint32_t want = a.nqb * (tix / a.pace_every);                                \
+                for (uint32_t spin = 0; spin < 200000u; ++spin) {                                  \
+                    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break; \
+                    __builtin_amdgcn_s_sleep(8);                                                   \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+        /* L2: the tile's 256 row norms -> LDS slot of its parity (one 1-KB piece, wave 0) */      \
+        if (METRIC == M_L2 && !DENSE && first && wave == 0)                                        \
+            VROD_GLDS16(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)tile * kBM) + lane * 16, lds + kLdsXn2 + (tile & 1) * 1024); \
+        W4_PHASE(FA0, BX, 0, 0, LDQ0, W4_DMU0)                                                     \
+        W4_PHASE(FA0, BY, 0, 1, W4_LDQ1, W4_DMU1)                                                  \
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                               \
+        VROD_BARRIER();                                                                            \
+        W4_PHASE(FA1, BY, 1, 1, W4_LDQ2, W4_DMU2)                                                  \
+        W4_PHASE(FA1, BX, 1, 0, LDQ3, W4_DMU3)                                                     \
+        stage_advance();                                                                           \
+        const bool last = kt == KT - 1;                                                            \
+        if (last) {                                                                                \
+            if constexpr (DENSE)                                                                   \
+                w4_dense_store_tile<METRIC>(a, qn2_l, wc * 128 + fr, tile * kBM + wr * 128 + fg * 4, qb * kBN + wc * 128 + fr); \
+            else                                                                                   \
+                w4_filter_tile<METRIC>(a, thr_l, qn2_l, xn_l + (tile & 1) * 256 + wr * 128 + fg * 4,        \
+                                       tile * kBM + wr * 128 + fg * 4, wc * 128 + fr, qb, rel_base, log, log_cnt); \
+            kt = 0; ++tile;                                                                        \
+        } else ++kt;                                                                               \
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                               \
+        VROD_BARRIER();                                                                            \
+        if (!DENSE && last && log_cnt[3] != 0u) {   /* every wave's appends are behind the barrier */ \
+            flush_log(a, log, log_cnt, qb, rel_base, tid);                                         \
+            if (tid == 0) log_cnt[3] = 0u;                                                         \
+            __syncthreads();                                                                       \
+        }                                                                                          \
+        ++it;                                                                                      \
+    }
+#define W4_LDQ1(j) W4_LOAD_A1(FA1, 1, l, j)
+#define W4_LDQ2(j) W4_LOAD_A1(FA0, 0, ln, j)
+#define W4_LDQ0x(j) W4_LOAD_B1(FBy, 1, l, j)
+#define W4_LDQ3x(j) W4_LOAD_B1(FBy, 0, ln, j)
+#define W4_LDQ0y(j) W4_LOAD_B1(FBx, 1, l, j)
+#define W4_LDQ3y(j) W4_LOAD_B1(FBx, 0, ln, j)
+#define W4_LDP_A(j) W4_LOAD_A1(FA0, 0, lds, j)
+#define W4_LDP_B(j) W4_LOAD_B1(FBx, 0, lds, j)
+        W4_LDP_A(0) W4_LDP_A(1) W4_LDP_A(2) W4_LDP_A(3) W4_LDP_A(4) W4_LDP_A(5) W4_LDP_A(6) W4_LDP_A(7)
+        W4_LDP_B(0) W4_LDP_B(1) W4_LDP_B(2) W4_LDP_B(3) W4_LDP_B(4) W4_LDP_B(5) W4_LDP_B(6) W4_LDP_B(7)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        VROD_BARRIER();   // every wave holds its first fragments: buffer 0's A_m0 / B_n0 may be restaged
+
+        uint32_t it = 0, kt = 0, tile = t0;
+        while (it < total_it) {
+            W4_ITER(FBx, FBy, W4_LDQ0x, W4_LDQ3x)
+            if (it >= total_it) break;
+            W4_ITER(FBy, FBx, W4_LDQ0y, W4_LDQ3y)
+        }
+#undef W4_LOAD_A1
+#undef W4_LOAD_B1
+#undef W4_PHASE_S
+#undef W4_PHASE
+#undef W4_DMU0
+#undef W4_DMU1
+#undef W4_DMU2
+#undef W4_DMU3
+#undef W4_ITER
+#undef W4_LDQ1
+#undef W4_LDQ2
+#undef W4_LDQ0x
+#undef W4_LDQ3x
+#undef W4_LDQ0y
+#undef W4_LDQ3y
+#undef W4_LDP_A
+#undef W4_LDP_B
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (!DENSE) {
+            flush_log(a, log, log_cnt, qb, rel_base, tid);
+            if (tid == 0) log_cnt[3] = 0u;
+            __syncthreads();
+        }
+    }
+}
+
 void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t s) {
     if (h.row_end <= h.row_begin) return;
     MfmaKernelArgs a{};
@@ -638,6 +1001,24 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
         KERNEL<TT, MM><<<grid, 512, kLdsTotal, s>>>(a);                                                     \
     } while (0)
     static const int gp = [] { const char* e = getenv("VROD_MFMA_GP"); return e ? atoi(e) : 0; }();
+    static const bool w4 = [] { const char* e = getenv("VROD_MFMA_W4"); return !e || e[0] != '0'; }();
+#define VROD_MFMA_W4K(MM, DN)                                                                               \
+    do {                                                                                                    \
+        static bool attr_set = false;                                                                       \
+        if (!attr_set) {                                                                                    \
+            (void)hipFuncSetAttribute((const void*)scan_mfma_w4_kernel<MM, DN>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotalW4);             \
+            attr_set = true;                                                                                \
+        }                                                                                                   \
+        scan_mfma_w4_kernel<MM, DN><<<grid, 256, kLdsTotalW4, s>>>(a);                                        \
+    } while (0)
+    // bf16 cosine only: the L2 instantiation fails the accumulator-file audit (hipcc parks values
+    // of its own in AGPRs across the tile loop there), so it is not built and L2 keeps the 8-wave form
+    if (dtype == DT_BF16 && h.metric == M_COSINE && w4 && !simple) {
+        if (h.dense_out) VROD_MFMA_W4K(M_COSINE, true); else VROD_MFMA_W4K(M_COSINE, false);
+        return;
+    }
+#undef VROD_MFMA_W4K
 #define VROD_MFMA_P(TT, MM, GPV, DN)                                                                            \
     do {                                                                                                    \
         static bool attr_set = false;                                                                       \
