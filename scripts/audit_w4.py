@@ -17,11 +17,19 @@ import sys
 def audit(path):
     text = open(path).read()
     bad = 0
-    for m in re.finditer(r"^(_ZN4vrod19scan_mfma_w4_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN4vrod19scan_mfma_w4_kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         inasm = False
         n_out = n_mfma = n_pro = 0
-        for line in body.split("\n"):
+        last_touch = first_mfma = -1
+        labels, branches = {}, []
+        for ln, line in enumerate(body.split("\n")):
+            lab = re.match(r"^(\.LBB\w+):", line)
+            if lab:
+                labels[lab.group(1)] = ln
+            br = re.search(r"\bs_c?branch\w*\s+(\.LBB\w+)", line.split(";")[0])
+            if br:
+                branches.append((ln, br.group(1)))
             if "ASMSTART" in line:
                 inasm = True
                 continue
@@ -30,15 +38,25 @@ def audit(path):
                 continue
             code = line.split(";")[0]
             if inasm:
-                n_mfma += "v_mfma" in code
+                if "v_mfma" in code:
+                    n_mfma += 1
+                    if first_mfma < 0:
+                        first_mfma = ln
                 continue
             if "scratch_" in code or ((("v_accvgpr" in code) or re.search(r"\ba\[?\d+", code)) and n_mfma > 0):
                 n_out += 1
                 print(f"{name}: compiler touches an AGPR / scratch: {line.strip()}")
             elif "v_accvgpr" in code or re.search(r"\ba\[?\d+", code):
                 n_pro += 1
+                last_touch = ln
+        # the parked values must not be re-read after the accumulators came alive: no branch from
+        # the MFMA region back to (or before) the last compiler AGPR use
+        for ln, target in branches:
+            if last_touch >= 0 and ln > first_mfma >= 0 and labels.get(target, 1 << 30) <= last_touch:
+                n_out += 1
+                print(f"{name}: back-edge from line {ln} to {target} (line {labels[target]}) re-enters the region where the compiler uses AGPRs")
         print(f"{name}: {n_mfma} asm MFMAs, {n_pro} compiler AGPR uses in the prologue (accumulators dead), {n_out} violations")
-        bad += n_out
+        bad += n_out + (n_mfma == 0)
     for m in re.finditer(r"\.amdhsa_kernel (_ZN4vrod19scan_mfma_w4_kernel\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
         name, desc = m.group(1), m.group(2)
         acc = int(re.search(r"\.amdhsa_accum_offset (\d+)", desc).group(1))

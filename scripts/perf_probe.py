@@ -31,5 +31,7 @@ if which in ("all", "cfg3s"):
     probe("cfg3-small 1Mx768 bf16 cos Q=1024 k=10", 1_000_000, 768, "bf16", "cosine", 1024, 10, steps=3)
 if which in ("all", "cfg3"):
     probe("cfg3 10Mx768 bf16 cos Q=1024 k=10", 10_000_000, 768, "bf16", "cosine", 1024, 10, steps=3)
+if which in ("l2bf16",):
+    probe("4Mx768 bf16 L2 Q=1024 k=10", 4_000_000, 768, "bf16", "l2", 1024, 10, steps=3)
 if which in ("cfg5",):
     probe("cfg5 10Mx1536 f32 cos Q=256 k=1000", 10_000_000, 1536, "f32", "cosine", 256, 1000, steps=2)

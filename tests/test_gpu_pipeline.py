@@ -153,3 +153,18 @@ def test_pipeline_protocol_errors(va, oracle):
     ix.add(raw)
     ix.search_begin_device(q, k, *o[0])
     ix.close()
+
+
+def test_more_query_blocks_than_work_group_slots(va, oracle):
+    """nq > 256 * 32: the 4-wave MFMA kernel takes one query block per work-group, so the launcher
+    splits the batch into several launches (33 query blocks on a 256-CU device)."""
+    raw = oracle.synth_rows(1, 0, 20000, 64, threads=8)
+    rq = oracle.synth_rows(2, 0, 8300, 64, threads=8)
+    k = 5
+    with va.Index(64, "bf16", "cosine") as ix:
+        ix.add(raw)
+        ix.set_path(2)
+        ids, sc = ix.search(rq, k)
+        assert ix.last_stats()["path"] == 2
+    oi, osc = oracle.search(raw, rq, k, 1, 0)
+    assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))

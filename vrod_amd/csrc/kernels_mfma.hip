@@ -34,6 +34,7 @@
 // list_compact_kernel, so every launch of this kernel is a pure function of its inputs.
 //
 // Roofline: MFMA.  Algorithmic flops per launch = 2 * nq * rows * dim  (SURVEY.md 8d).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -95,6 +96,7 @@ struct MfmaKernelArgs {
     uint32_t dense_ld;
     uint32_t* pace;         // [nstrips] arrival counters of the sibling work-groups (zeroed per launch)
     uint32_t pace_every;    // re-align the siblings of a strip every this many tiles (0 = never)
+    uint32_t qb_base;       // 4-wave kernel: first query block of this launch (nqb <= slots per launch)
 };
 
 template <int METRIC>
@@ -125,6 +127,15 @@ __device__ __forceinline__ bool wg_assignment(const MfmaKernelArgs& a, uint32_t&
     return true;
 }
 
+// log_cnt[0..2] = 0 with the zero made in a VGPR on the spot.  (As a plain store hipcc keeps a
+// zero vector alive across the whole kernel -- in AGPRs where it may, which the 4-wave kernel
+// owns: scripts/audit_w4.py.)
+__device__ __forceinline__ void lds_zero3(uint32_t* p) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %1 offset:4\n\tds_write_b32 %0, %1 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 :: "v"(addr), "v"(0u) : "memory");
+}
+
 // Drain the LDS log into the per-query lists.  Called by ALL threads at the same program
 // point; the leading barrier makes sure every wave's appends (a wave group may still be in
 // its tile filter) are in the log.  Uses three block barriers.
@@ -137,7 +148,7 @@ __device__ __forceinline__ void flush_log(const MfmaKernelArgs& a, uint2* log, u
         global_append(a, qb * kBN + (e.y >> 24), e.x, rel_base + (e.y & 0xFFFFFFu));
     }
     __syncthreads();
-    if (tid == 0) { log_cnt[0] = 0; log_cnt[1] = 0; log_cnt[2] = 0; }
+    if (tid == 0) lds_zero3(log_cnt);
     __syncthreads();
 }
 
@@ -793,7 +804,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
     const uint32_t t1 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * (strip + 1) / a.nstrips);
     if (t0 >= t1) return;
 
-    if (tid == 0) { log_cnt[0] = 0; log_cnt[1] = 0; log_cnt[2] = 0; log_cnt[3] = 0; }
+    if (tid == 0) { lds_zero3(log_cnt); lds_zero3(log_cnt + 1); }
     __syncthreads();
 
     const uint32_t KT = a.ld_bytes >> 7;
@@ -807,7 +818,11 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
     const uint64_t piece_stride = 8ull * a.ld_bytes;
     const uint32_t total_it = (t1 - t0) * KT;
 
-    for (uint32_t qb = qb0; qb < a.nqb; qb += qb_step) {
+    // ONE query block per work-group: a loop over query blocks here would re-enter the prologue with the
+    // accumulator file live in hipcc's eyes (it parks kernel-entry values in AGPRs up to the first MFMA);
+    // the launcher splits batches of more than `slots` query blocks into several launches instead
+    const uint32_t qb = a.qb_base + qb0;
+    {
         float* thr_l = reinterpret_cast<float*>(lds + kLdsThr);
         float* qn2_l = reinterpret_cast<float*>(lds + kLdsQn2);
         const float* xn_l = reinterpret_cast<const float*>(lds + kLdsXn2);
@@ -1012,10 +1027,18 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
         }                                                                                                   \
         scan_mfma_w4_kernel<MM, DN><<<grid, 256, kLdsTotalW4, s>>>(a);                                        \
     } while (0)
-    // bf16 cosine only: the L2 instantiation fails the accumulator-file audit (hipcc parks values
-    // of its own in AGPRs across the tile loop there), so it is not built and L2 keeps the 8-wave form
-    if (dtype == DT_BF16 && h.metric == M_COSINE && w4 && !simple) {
-        if (h.dense_out) VROD_MFMA_W4K(M_COSINE, true); else VROD_MFMA_W4K(M_COSINE, false);
+    if (dtype == DT_BF16 && w4 && !simple) {
+        const uint32_t nqb_total = a.nqb;
+        for (uint32_t qb_base = 0; qb_base < nqb_total; qb_base += a.slots) {   // one launch unless nq > 256 * slots
+            a.qb_base = qb_base;
+            a.nqb = std::min<uint32_t>(a.slots, nqb_total - qb_base);
+            a.strips_per_xcd = a.slots / a.nqb;
+            a.nstrips = 8 * a.strips_per_xcd;
+            a.pace_every = (h.pace && a.nqb > 1 && pace_env > 0) ? (uint32_t)pace_env : 0u;
+            if (a.pace_every && (qb_base > 0 || !h.pace_is_zero)) (void)hipMemsetAsync(a.pace, 0, a.nstrips * sizeof(uint32_t), s);
+            if (h.metric == M_COSINE) { if (h.dense_out) VROD_MFMA_W4K(M_COSINE, true); else VROD_MFMA_W4K(M_COSINE, false); }
+            else { if (h.dense_out) VROD_MFMA_W4K(M_L2, true); else VROD_MFMA_W4K(M_L2, false); }
+        }
         return;
     }
 #undef VROD_MFMA_W4K
