@@ -248,7 +248,8 @@ def main():
         else:
             achieved = acc["scan_flops"] / (acc["scan_ms"] * 1e-3) / 1e12 if acc["scan_ms"] else 0.0
             peak, unit = PEAK["mfma_bf16" if wl["dtype"] == "bf16" else "mfma_f32"]
-            kernel = "scan_mfma_phased_kernel"
+            # bf16: the 4-wave kernel (VROD_MFMA_W4=0 selects the 8-wave phased form); fp32: phased
+            kernel = "scan_mfma_w4_kernel" if wl["dtype"] == "bf16" and os.environ.get("VROD_MFMA_W4", "1") != "0" else "scan_mfma_phased_kernel"
             per_launch = acc["scan_flops"] / max(acc["launches"], 1)
             work_key = "algorithmic_flops_per_launch"
         traffic = None

@@ -140,6 +140,14 @@ __global__ __launch_bounds__(256) void gemm_w4(const Args a) {
         const uint32_t idx = wave * 4 + i;
         const uint32_t p = (idx >> 3) * 16 + (idx & 7) + h * 8;
         char* l = lds + (buf & 1) * kStage + (is_b ? 32768 : 0) + p * 1024;
+        if ((a.flags & 8) && is_b) return;                 // B staged once (timing only)
+        if (a.flags & 4) {                                 // issue with all lanes off (timing only)
+            const uint64_t ex = __builtin_amdgcn_read_exec();
+            asm volatile("s_mov_b64 exec, 0" ::: "memory");
+            GLDS16((is_b ? ub_src : ua_src) + (uint64_t)p * piece_stride, l);
+            asm volatile("s_mov_b64 exec, %0" :: "s"(ex) : "memory");
+            return;
+        }
         GLDS16((is_b ? ub_src : ua_src) + (uint64_t)p * piece_stride, l);
     };
     // advance the staging pointers by one K-tile (clamped at the end of the strip: the last

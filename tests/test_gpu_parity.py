@@ -209,8 +209,9 @@ def test_merge_topk_device_matches_oracle(va, oracle):
 # ---------------------------------------------------------------- scale / structure cases
 def test_mfma_path_splits_launches_past_2pow24_rows(va, oracle):
     """Rows are addressed relative to a launch's first tile with 24 bits: a 17M-row shard needs
-    two launches per stage.  64-d bf16 keeps it at 2 GB; oracle on 8 threads."""
-    n, dim, nq, k = (1 << 24) + 300_001, 64, 12, 10
+    two launches for its last stage (sample 64k rows -> stage to ~1.1M -> 17.9M rows).  64-d bf16
+    keeps it at 2.4 GB; oracle on 8 threads."""
+    n, dim, nq, k = (1 << 24) + 2_300_001, 64, 12, 10
     with va.Index(dim, "bf16", "cosine") as ix:
         ix.add_synthetic(1, 0, n)
         ix.set_path(va.PATH_MFMA)
@@ -219,7 +220,7 @@ def test_mfma_path_splits_launches_past_2pow24_rows(va, oracle):
         st = ix.last_stats()
     raw = oracle.synth_rows(1, 0, n, dim, threads=8)
     oi, osc = oracle.search(raw, rq, k, 1, 0, threads=8)
-    assert_same(ids, sc, oi, osc, "17M rows")
+    assert_same(ids, sc, oi, osc, "19M rows")
     assert st["fallback_queries"] == 0 and st["scan_launches"] >= 4
 
 

@@ -994,7 +994,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     a.row_end = h.row_end;
     a.dense_out = h.dense_out;
     a.dense_ld = h.dense_ld;
-    static const int pace_env = [] { const char* e = getenv("VROD_MFMA_PACE"); return e ? atoi(e) : 8; }();
+    static const int pace_env = [] { const char* e = getenv("VROD_MFMA_PACE"); return e ? atoi(e) : 16; }();
     a.pace = h.pace;
     int grid = num_cus / 8 * 8;
     if (grid < 8) grid = 8;
