@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256) void gemm_w4(const Args a) {
         const bool first = (it % KT) == 0;                                                         \
         PHASE2(FA0, BX, 0, 0, LDQ0, DMU0)                                                          \
         PHASE2(FA0, BY, 0, 1, LDQ1, DMU1)                                                          \
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                               \
-        BARRIER();                                                                                 \
+        if (!(a.flags & 2)) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");           \
+        if (!(a.flags & 16)) BARRIER();                                                            \
         PHASE2(FA1, BY, 1, 1, LDQ2, DMU2)                                                          \
         PHASE2(FA1, BX, 1, 0, LDQ3, DMU3)                                                          \
         stage_advance();                                                                           \
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256) void gemm_w4(const Args a) {
                 best[n] = fmaxf(best[n], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));             \
             });                                                                                    \
         }                                                                                          \
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                               \
-        BARRIER();                                                                                 \
+        if (!(a.flags & 2)) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");           \
+        if (!(a.flags & 16)) BARRIER();                                                            \
         ++it;                                                                                      \
     }
 #define DMU0(j) stage_unit(it & 1, false, 0, j);

@@ -883,22 +883,22 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #define W4_DMU1(j) stage_unit(it & 1, true, 0, j);
 #define W4_DMU2(j) stage_unit(it & 1, true, 1, j);
 #define W4_DMU3(j) stage_unit(it & 1, false, 1, j);
+#define W4_VMWAIT "s_waitcnt vmcnt(16) lgkmcnt(0)"
 #define W4_ITER(BX, BY, LDQ0, LDQ3)                                                                \
     {                                                                                              \
         const char* l = lds + (it & 1) * kStageBytes;                                              \
         const char* ln = lds + ((it + 1) & 1) * kStageBytes;                                       \
         const bool first = kt == 0;                                                                \
-        /* pacing of the sibling work-groups (see the phased kernel) */                            \
-        if (a.pace_every && first && it > 0 && tid == 0) {                                         \
-            const uint32_t tix = tile - t0;                                                        \
-            if (tix % a.pace_every == 0) {                                                         \
-                uint32_t* ctr = a.pace + strip;                                                    \
-                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       \
-                const uint32_t want = a.nqb * (tix / a.pace_every);                                \
-                for (uint32_t spin = 0; spin < 200000u; ++spin) {                                  \
-                    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break; \
-                    __builtin_amdgcn_s_sleep(8);                                                   \
-                }                                                                                  \
+        /* pacing of the sibling work-groups (see the phased kernel), here in units of K-tiles: with  \
+           the staging two K-tiles ahead no work-group ever waits for HBM, so nothing else keeps   \
+           the siblings of a strip together */                                                     \
+        if (a.pace_every && it > 0 && (it % a.pace_every) == 0 && tid == 0) {                      \
+            uint32_t* ctr = a.pace + strip;                                                        \
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
+            const uint32_t want = a.nqb * (it / a.pace_every);                                     \
+            for (uint32_t spin = 0; spin < 200000u; ++spin) {                                      \
+                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break; \
+                __builtin_amdgcn_s_sleep(4);                                                       \
             }                                                                                      \
         }                                                                                          \
         /* L2: the tile's 256 row norms -> LDS slot of its parity (one 1-KB piece, wave 0) */      \
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
             VROD_GLDS16(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)tile * kBM) + lane * 16, lds + kLdsXn2 + (tile & 1) * 1024); \
         W4_PHASE(FA0, BX, 0, 0, LDQ0, W4_DMU0)                                                     \
         W4_PHASE(FA0, BY, 0, 1, W4_LDQ1, W4_DMU1)                                                  \
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                               \
+        asm volatile(W4_VMWAIT ::: "memory");                                                      \
         VROD_BARRIER();                                                                            \
         W4_PHASE(FA1, BY, 1, 1, W4_LDQ2, W4_DMU2)                                                  \
         W4_PHASE(FA1, BX, 1, 0, LDQ3, W4_DMU3)                                                     \
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
                                        tile * kBM + wr * 128 + fg * 4, wc * 128 + fr, qb, rel_base, log, log_cnt); \
             kt = 0; ++tile;                                                                        \
         } else ++kt;                                                                               \
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                               \
+        asm volatile(W4_VMWAIT ::: "memory");                                                      \
         VROD_BARRIER();                                                                            \
         if (!DENSE && last && log_cnt[3] != 0u) {   /* every wave's appends are behind the barrier */ \
             flush_log(a, log, log_cnt, qb, rel_base, tid);                                         \
@@ -952,6 +952,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #undef W4_LOAD_B1
 #undef W4_PHASE_S
 #undef W4_PHASE
+#undef W4_VMWAIT
 #undef W4_DMU0
 #undef W4_DMU1
 #undef W4_DMU2
@@ -1017,6 +1018,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     } while (0)
     static const int gp = [] { const char* e = getenv("VROD_MFMA_GP"); return e ? atoi(e) : 0; }();
     static const bool w4 = [] { const char* e = getenv("VROD_MFMA_W4"); return !e || e[0] != '0'; }();
+    static const int pace_kt = [] { const char* e = getenv("VROD_MFMA_PACE_KT"); return e ? atoi(e) : 192; }();
 #define VROD_MFMA_W4K(MM, DN)                                                                               \
     do {                                                                                                    \
         static bool attr_set = false;                                                                       \
@@ -1034,7 +1036,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
             a.nqb = std::min<uint32_t>(a.slots, nqb_total - qb_base);
             a.strips_per_xcd = a.slots / a.nqb;
             a.nstrips = 8 * a.strips_per_xcd;
-            a.pace_every = (h.pace && a.nqb > 1 && pace_env > 0) ? (uint32_t)pace_env : 0u;
+            a.pace_every = (h.pace && a.nqb > 1 && pace_kt > 0) ? (uint32_t)pace_kt : 0u;   // K-tiles
             if (a.pace_every && (qb_base > 0 || !h.pace_is_zero)) (void)hipMemsetAsync(a.pace, 0, a.nstrips * sizeof(uint32_t), s);
             if (h.metric == M_COSINE) { if (h.dense_out) VROD_MFMA_W4K(M_COSINE, true); else VROD_MFMA_W4K(M_COSINE, false); }
             else { if (h.dense_out) VROD_MFMA_W4K(M_L2, true); else VROD_MFMA_W4K(M_L2, false); }
