@@ -143,7 +143,7 @@ int vrod_merge_topk_packed_device(int device, int metric, const void *d_packed, 
 
 /* --- knobs & introspection -------------------------------------------------- */
 int vrod_index_set_path(vrod_index *idx, int path);      /* VROD_PATH_* (default AUTO) */
-int vrod_index_set_profiling(vrod_index *idx, int on);   /* HIP-event timing of kernels */
+int vrod_index_set_profiling(vrod_index *idx, int on);   /* 1: scan_ms (events attached to the scan dispatches), 2: + total_ms (stream markers) */
 int vrod_index_last_stats(const vrod_index *idx, vrod_search_stats *out);
 const char *vrod_last_error(void);                       /* thread-local text */
 const char *vrod_version(void);

@@ -7,7 +7,7 @@ import vrod_amd as va
 def probe(name, n, dim, dtype, metric, nq, k, steps=5, path=0):
     ix = va.Index(dim, dtype, metric)
     t = time.time(); ix.add_synthetic(1, 0, n); torch.cuda.synchronize(); tg = time.time() - t
-    ix.set_profiling(True); ix.set_path(path)
+    ix.set_profiling(2); ix.set_path(path)
     oi = torch.empty((nq, k), dtype=torch.int64, device="cuda"); osc = torch.empty((nq, k), dtype=torch.float32, device="cuda")
     ix.search_synthetic_device(2, 0, nq, k, oi, osc)  # warmup
     res = []

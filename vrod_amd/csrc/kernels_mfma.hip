@@ -977,6 +977,8 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 }
 
 void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t s) {
+    const LaunchEvents lev = g_launch_events;   // attached to the dispatch (first / last of a split batch)
+    g_launch_events = LaunchEvents{};
     if (h.row_end <= h.row_begin) return;
     MfmaKernelArgs a{};
     a.corpus = (const char*)h.corpus;
@@ -1014,7 +1016,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);               \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        KERNEL<TT, MM><<<grid, 512, kLdsTotal, s>>>(a);                                                     \
+        hipExtLaunchKernelGGL((KERNEL<TT, MM>), dim3(grid), dim3(512), kLdsTotal, s, lev.start, lev.stop, 0, a); \
     } while (0)
     static const int gp = [] { const char* e = getenv("VROD_MFMA_GP"); return e ? atoi(e) : 0; }();
     static const bool w4 = [] { const char* e = getenv("VROD_MFMA_W4"); return !e || e[0] != '0'; }();
@@ -1027,13 +1029,15 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotalW4);             \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        scan_mfma_w4_kernel<MM, DN><<<grid, 256, kLdsTotalW4, s>>>(a);                                        \
+        hipExtLaunchKernelGGL((scan_mfma_w4_kernel<MM, DN>), dim3(grid), dim3(256), kLdsTotalW4, s,            \
+                              first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr, 0, a);        \
     } while (0)
     if (dtype == DT_BF16 && w4 && !simple) {
         const uint32_t nqb_total = a.nqb;
         for (uint32_t qb_base = 0; qb_base < nqb_total; qb_base += a.slots) {   // one launch unless nq > 256 * slots
             a.qb_base = qb_base;
             a.nqb = std::min<uint32_t>(a.slots, nqb_total - qb_base);
+            const bool first_launch = qb_base == 0, last_launch = qb_base + a.slots >= nqb_total;
             a.strips_per_xcd = a.slots / a.nqb;
             a.nstrips = 8 * a.strips_per_xcd;
             a.pace_every = (h.pace && a.nqb > 1 && pace_kt > 0) ? (uint32_t)pace_kt : 0u;   // K-tiles
@@ -1052,7 +1056,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);               \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        scan_mfma_phased_kernel<TT, MM, GPV, DN><<<grid, 512, kLdsTotal, s>>>(a);                               \
+        hipExtLaunchKernelGGL((scan_mfma_phased_kernel<TT, MM, GPV, DN>), dim3(grid), dim3(512), kLdsTotal, s, lev.start, lev.stop, 0, a); \
     } while (0)
 #define VROD_MFMA_BOTH(TT, MM)                                                                              \
     do {                                                                                                    \

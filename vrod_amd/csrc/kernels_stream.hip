@@ -203,9 +203,11 @@ static void dispatch_it(const T* corpus, uint32_t ld, uint64_t nrows, const floa
     while ((upr & ((1u << lpr_log2) - 1)) != 0) --lpr_log2;
     const int it = (int)(upr >> lpr_log2);
     const size_t lds = (size_t)NQ * ld * sizeof(float) + (size_t)NQ * (sizeof(uint32_t) << StreamHist<NQ>::HB) + 32;
+    const LaunchEvents lev = g_launch_events;
+    g_launch_events = LaunchEvents{};
 #define VROD_LAUNCH(ITV, UNR)                                                                   \
-    scan_stream_kernel<T, METRIC, NQ, ITV, UNR><<<num_blocks, 256, lds, s>>>(                   \
-        corpus, ld, nrows, q, scores, score_ld, lpr_log2, it, ghist, kp)
+    hipExtLaunchKernelGGL((scan_stream_kernel<T, METRIC, NQ, ITV, UNR>), dim3(num_blocks), dim3(256), lds, s, \
+                          lev.start, lev.stop, 0, corpus, ld, nrows, q, scores, score_ld, lpr_log2, it, ghist, kp)
     switch (it) {
         case 1: VROD_LAUNCH(1, 8); break;
         case 2: VROD_LAUNCH(2, 4); break;
@@ -232,7 +234,7 @@ static void dispatch_nq(const T* corpus, uint32_t ld, uint64_t nrows, const floa
 void launch_scan_stream(const void* d_corpus, int dtype, int metric, uint32_t ld, uint64_t nrows,
                         const float* d_q, int nq_pad, float* d_scores, uint64_t score_ld,
                         uint32_t* d_hist, uint32_t kp, hipStream_t s) {
-    if (!nrows) return;
+    if (!nrows) { g_launch_events = LaunchEvents{}; return; }
     // 64 rows per wave step, 4 waves per block.  2 blocks per CU (8 waves x 12 KB of loads in
     // flight) measured best on MI355X: 6.46 TB/s at 1M x 768 fp32 vs 5.9 TB/s with 8 blocks per
     // CU, whose per-block histogram set-up/flush then costs 10 % (profiles/r01).

@@ -231,7 +231,7 @@ struct Timer {
     Pending& P;
     Timer(vrod_index* i, Pending& p) : idx(i), P(p) {}
     size_t mark() {
-        if (!idx->profiling) return 0;
+        if (idx->profiling < 2) return 0;   // stream markers only at level 2 (total_ms)
         if (P.ev_used == P.ev.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return 0;
@@ -239,6 +239,20 @@ struct Timer {
         }
         (void)hipEventRecord(P.ev[P.ev_used], idx->stream);
         return P.ev_used++;
+    }
+    // two fresh events for the next scan launch (attached to the dispatch, not recorded as markers)
+    void arm(size_t& a, size_t& b) {
+        a = b = 0;
+        if (!idx->profiling) return;
+        while (P.ev.size() < P.ev_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            P.ev.push_back(e);
+        }
+        a = P.ev_used++;
+        b = P.ev_used++;
+        g_launch_events.start = P.ev[a];
+        g_launch_events.stop = P.ev[b];
     }
     float ms(size_t a, size_t b) {
         float m = 0.f;
@@ -442,11 +456,11 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
             int nqp = 1;
             while (nqp < nqc) nqp <<= 1;
             if (q0 > 0) HIP_TRY(hipMemsetAsync(d_hist, 0, hist_words * 4, s));
-            const size_t a = tm.mark();
+            size_t a, b;
+            tm.arm(a, b);
             launch_scan_stream(idx->corpus, idx->dtype, idx->metric, idx->ld, N,
                                P.q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, idx->scores.as<float>(), score_ld,
                                d_hist, kp, s);
-            const size_t b = tm.mark();
             P.scan_pairs.push_back({a, b});
             st.scan_launches++;
             st.scan_bytes += (double)N * row_bytes_alg;
@@ -478,9 +492,9 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
             MfmaScanArgs d = a;
             d.row_begin = 0; d.row_end = sp.S; d.dense_out = idx->scores.as<float>(); d.dense_ld = dense_ld;
             d.pace = pace_base; d.pace_is_zero = true; ++pace_launch;
-            const size_t e0 = tm.mark();
+            size_t e0, e1;
+            tm.arm(e0, e1);
             launch_scan_mfma(d, idx->dtype, idx->num_cus, s);
-            const size_t e1 = tm.mark();
             P.scan_pairs.push_back({e0, e1});
             st.scan_launches++;
             st.scan_bytes += (double)dense_ld * row_bytes_alg;
@@ -496,9 +510,9 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
                 a.pace = pace_base + (pace_launch % kPaceRegions) * kPaceWords;
                 a.pace_is_zero = pace_launch < kPaceRegions;   // later launches reuse a region: memset
                 ++pace_launch;
-                const size_t e0 = tm.mark();
+                size_t e0, e1;
+                tm.arm(e0, e1);
                 launch_scan_mfma(a, idx->dtype, idx->num_cus, s);
-                const size_t e1 = tm.mark();
                 P.scan_pairs.push_back({e0, e1});
                 st.scan_launches++;
                 st.scan_bytes += (double)(end - lo / kRowTile * kRowTile) * row_bytes_alg;
@@ -585,7 +599,7 @@ static int search_complete(vrod_index* idx, Pending& P) {
     }
     if (idx->profiling) {
         for (auto& pr : P.scan_pairs) st.scan_ms += tm.ms(pr.first, pr.second);
-        st.total_ms = tm.ms(P.t0, P.t1);
+        if (idx->profiling >= 2) st.total_ms = tm.ms(P.t0, P.t1);
     }
     idx->stats = st;
     return VROD_OK;
@@ -869,7 +883,7 @@ int vrod_index_set_path(vrod_index* idx, int path) {
 
 int vrod_index_set_profiling(vrod_index* idx, int on) {
     if (!idx) return fail(VROD_ERR_INVALID_ARG, "idx is null");
-    idx->profiling = on ? 1 : 0;
+    idx->profiling = on < 0 ? 0 : on > 2 ? 2 : on;
     return VROD_OK;
 }
 

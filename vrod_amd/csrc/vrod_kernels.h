@@ -1,6 +1,7 @@
 // vrod_kernels.h -- host-callable launchers of the HIP kernels (internal to libvrod_hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace vrod {
@@ -118,6 +119,12 @@ void launch_rescore_all(const void* d_corpus, int dtype, int metric, uint32_t di
                         const float* d_q1, uint64_t nrows, float* d_out, hipStream_t s);
 
 // ---- kernels_mfma.hip : batched Q.K^T scan with fused threshold filter
+// Timing of the dominant scan launches without marker packets: the launcher of the next scan
+// kernel attaches these events to the dispatch itself (hipExtLaunchKernelGGL), then clears them.
+// A marker recorded on the stream costs ~5 us of serialisation on each side of the kernel.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+inline thread_local LaunchEvents g_launch_events;
+
 struct MfmaScanArgs {
     const void* corpus;     // [capacity][ld] bf16 or f32
     const void* queries;    // [nq_pad][ld] same dtype (nq_pad multiple of 256)

@@ -94,8 +94,9 @@ class Index:
     def set_path(self, path: int):
         check(self._L.vrod_index_set_path(self._h, int(path)))
 
-    def set_profiling(self, on: bool):
-        check(self._L.vrod_index_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, level):
+        """0/False: off; 1/True: scan_ms (events attached to the scan dispatches); 2: + total_ms."""
+        check(self._L.vrod_index_set_profiling(self._h, int(level)))
 
     def last_stats(self) -> dict:
         st = SearchStats()
