@@ -290,3 +290,17 @@ def test_max_k(va, oracle, path):
     raw = oracle.synth_rows(1, 0, 30000, 64, threads=8)
     rq = oracle.synth_rows(2, 0, 3, 64)
     run_case(va, oracle, raw, rq, va.MAX_K, "f32", "cosine", path)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+@pytest.mark.parametrize("dim", [40, 129, 300, 768])   # bf16 K-tiles per row: 1, 3 (odd), 5, 12
+def test_bf16_4wave_kernel_ktile_counts(va, oracle, dim, metric):
+    """The 4-wave MFMA kernel alternates two register roles per K-tile and peels the first K-tile
+    of every corpus tile (C = 0 form): odd and single K-tile rows, two query blocks (one padded),
+    staged plan (N > list capacity), unnormalised rows for the L2 norm path."""
+    rng = np.random.default_rng(dim)
+    n, nq, k = 21000, 300, 10
+    raw = (rng.standard_normal((n, dim)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    rq = rng.standard_normal((nq, dim)).astype(np.float32)
+    st = run_case(va, oracle, raw, rq, k, "bf16", metric, 2)
+    assert st["path"] == 2 and st["scan_launches"] >= 2
