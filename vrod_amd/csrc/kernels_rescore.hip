@@ -83,55 +83,83 @@ __global__ __launch_bounds__(64) void rescore_kernel(const T* __restrict__ corpu
     const int sub = lane / LPC, part = lane % LPC;
 
     float acc = 0.0f;
-    // the row gather of chunk c+1 is issued before the chain of chunk c runs (the chain is
-    // sequential and latency-bound; the loads must not be)
-    u32x4 v[NI];
-    auto fetch = [&](uint32_t j0) {
+    // The chain is sequential and latency-bound; the row gathers must not be: the loads of chunks
+    // c+1 .. c+D-1 are in flight while the chain of chunk c runs (ring of D register sets; with
+    // one chunk ahead a 768-d re-score waited a full gather latency twelve times: 38-44 us).
+    constexpr int D = 3;
+    u32x4 v[D][NI];
+    auto fetch = [&](u32x4 (&vs)[NI], uint32_t j0) {
         const uint32_t e0 = j0 + part * EPU;  // first element this lane fetches
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
-            v[it] = u32x4{0u, 0u, 0u, 0u};
+            vs[it] = u32x4{0u, 0u, 0u, 0u};
             if (it < ni_used) {
                 const uint32_t row = __shfl(my_row, it * RPI + sub);
-                if (e0 < ld) v[it] = *reinterpret_cast<const u32x4*>(corpus + (uint64_t)row * ld + e0);
+                if (e0 < ld) vs[it] = *reinterpret_cast<const u32x4*>(corpus + (uint64_t)row * ld + e0);
             }
         }
     };
-    fetch(0);
-    for (uint32_t j0 = 0; j0 < dim; j0 += 64) {
 #pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            float* t = tile + (it * RPI + sub) * kTileStride + part * EPU;
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<u32x4*>(t) = v[it];
-            } else {
-                *reinterpret_cast<u32x4*>(t) = u32x4{v[it].x << 16, v[it].x & 0xFFFF0000u, v[it].y << 16, v[it].y & 0xFFFF0000u};
-                *reinterpret_cast<u32x4*>(t + 4) = u32x4{v[it].z << 16, v[it].z & 0xFFFF0000u, v[it].w << 16, v[it].w & 0xFFFF0000u};
+    for (int d = 0; d < D; ++d)
+        if ((uint32_t)d * 64 < dim) fetch(v[d], d * 64);
+    for (uint32_t jb = 0; jb < dim; jb += 64 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const uint32_t j0 = jb + d * 64;
+            if (j0 >= dim) break;
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                float* t = tile + (it * RPI + sub) * kTileStride + part * EPU;
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<u32x4*>(t) = v[d][it];
+                } else {
+                    *reinterpret_cast<u32x4*>(t) = u32x4{v[d][it].x << 16, v[d][it].x & 0xFFFF0000u, v[d][it].y << 16, v[d][it].y & 0xFFFF0000u};
+                    *reinterpret_cast<u32x4*>(t + 4) = u32x4{v[d][it].z << 16, v[d][it].z & 0xFFFF0000u, v[d][it].w << 16, v[d][it].w & 0xFFFF0000u};
+                }
             }
-        }
-        if (j0 + 64 < dim) fetch(j0 + 64);
-        // the tile (and q_lds on the first pass) is wave-private: in-order LDS + a compiler fence
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t jn = dim - j0 < 64 ? dim - j0 : 64;
-        const float* trow = tile + lane * kTileStride;
-        for (uint32_t l = 0; l < jn; l += 4) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(trow + l);
-            const f32x4 qq = *reinterpret_cast<const f32x4*>(q_lds + j0 + l);
+            if (j0 + 64 * D < dim) fetch(v[d], j0 + 64 * D);
+            // the tile (and q_lds on the first pass) is wave-private: in-order LDS + a compiler fence
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t jn = dim - j0 < 64 ? dim - j0 : 64;
+            const float* trow = tile + lane * kTileStride;
+            if (jn == 64) {
+                // whole chunk: fully unrolled, so the LDS reads and the products (independent)
+                // run ahead of the one thing that is serial, the 64 dependent adds
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (l + e < jn) {
-                    if constexpr (METRIC == M_COSINE) {
-                        acc = add_rn(acc, mul_rn(qq[e], x[e]));
-                    } else {
-                        const float d = sub_rn(qq[e], x[e]);
-                        acc = add_rn(acc, mul_rn(d, d));
+                for (uint32_t l = 0; l < 64; l += 4) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(trow + l);
+                    const f32x4 qq = *reinterpret_cast<const f32x4*>(q_lds + j0 + l);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (METRIC == M_COSINE) {
+                            acc = add_rn(acc, mul_rn(qq[e], x[e]));
+                        } else {
+                            const float dd = sub_rn(qq[e], x[e]);
+                            acc = add_rn(acc, mul_rn(dd, dd));
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t l = 0; l < jn; l += 4) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(trow + l);
+                    const f32x4 qq = *reinterpret_cast<const f32x4*>(q_lds + j0 + l);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (l + e < jn) {
+                            if constexpr (METRIC == M_COSINE) {
+                                acc = add_rn(acc, mul_rn(qq[e], x[e]));
+                            } else {
+                                const float dd = sub_rn(qq[e], x[e]);
+                                acc = add_rn(acc, mul_rn(dd, dd));
+                            }
+                        }
                     }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
     if constexpr (ALL) {
         if (valid) out[slot] = acc;
