@@ -77,9 +77,13 @@ typedef struct {
 } vrod_search_stats;
 
 /* --- lifecycle ------------------------------------------------------------- */
-/* device_ids/n_devices: the GPUs the corpus is sharded over (contiguous row ranges,
- * SURVEY.md 8e). n_devices == 1 in this build for one handle; one handle per process
- * per GPU is the multi-GPU deployment (see vrod_search_device + vrod_merge_topk_device). */
+/* device_ids/n_devices: the GPUs the corpus is sharded over.  n_devices <= 1: one
+ * handle drives one GPU (the deployment bench.py measures is one process and one handle per GPU,
+ * see vrod_search_device + vrod_merge_topk_device).  n_devices > 1 (at most 64, an id may repeat):
+ * ONE handle owns a shard on every listed device; rows are dealt to the shards in blocks of 65536
+ * in insertion order, vrod_search runs on all of them at once and merges on device_ids[0], ids are
+ * global insertion indices as for a single device.  Device pointers passed to such a handle live
+ * on device_ids[0]; the pipelined _begin_/_end form is per device and returns VROD_ERR_UNSUPPORTED. */
 int vrod_index_create(vrod_index **out, uint32_t dim, int dtype, int metric,
                       const int *device_ids, int n_devices);
 int vrod_index_destroy(vrod_index *idx);

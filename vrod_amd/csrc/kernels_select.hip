@@ -578,6 +578,25 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(int metric, const uint6
     }
 }
 
+// Multi-device handle: lists gathered from G shards hold LOCAL row indices; rows are dealt to the
+// shards in blocks of B (global r -> shard (r / B) % G, local (r / (B*G)) * B + r % B), so
+// global = ((local / B) * G + shard) * B + local % B.  Monotonic within a shard: a list sorted by
+// (score, local row) stays sorted by (score, global id).
+__global__ __launch_bounds__(256) void shard_ids_to_global_kernel(uint64_t* __restrict__ ids, uint64_t list_stride, uint32_t n_lists,
+                                                                  uint64_t per_list, uint64_t block_rows, uint64_t id_offset) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_list) return;
+    const uint32_t g = blockIdx.y;
+    uint64_t& id = ids[(uint64_t)g * list_stride + i];
+    if (id != UINT64_MAX) id = ((id / block_rows) * n_lists + g) * block_rows + id % block_rows + id_offset;
+}
+
+void launch_shard_ids_to_global(uint64_t* d_ids, uint64_t list_stride, uint32_t n_lists, uint64_t per_list,
+                                uint64_t block_rows, uint64_t id_offset, hipStream_t s) {
+    if (!per_list || !n_lists) return;
+    shard_ids_to_global_kernel<<<dim3((unsigned)((per_list + 255) / 256), n_lists), 256, 0, s>>>(d_ids, list_stride, n_lists, per_list, block_rows, id_offset);
+}
+
 void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores, uint64_t list_stride_ids,
                        uint64_t list_stride_scores, uint32_t n_lists, uint32_t nq, uint32_t k,
                        uint64_t* d_out_ids, float* d_out_scores, hipStream_t s) {

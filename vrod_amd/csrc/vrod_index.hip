@@ -131,6 +131,15 @@ struct vrod_index {
 
     uint32_t n_pending() const { return n_begun - n_ended; }
 
+    // --- composite handle (vrod_index_create with n_devices > 1): the rows are dealt to the
+    // shards in blocks of kShardBlock rows (global row r -> shard (r / B) % G, local row
+    // (r / (B*G)) * B + r % B), every shard is a complete single-device index of its own, and a
+    // search runs on all of them at once, then gathers and merges on the first device.
+    std::vector<vrod_index*> shards;
+    DevBuf gather;                       // [G][nq*k ids | nq*k scores] on shards[0]'s device
+    std::vector<DevBuf> sh_q, sh_ids, sh_scores;   // per shard, on its device
+    bool composite() const { return !shards.empty(); }
+
     size_t row_bytes() const { return (size_t)ld * esize; }
 };
 
@@ -651,6 +660,127 @@ static int order_after_caller(vrod_index* idx, void* stream) {
     return VROD_OK;
 }
 
+// ------------------------------------------------------------------ composite (multi-device) handle
+static const uint64_t kShardBlock = 65536;
+
+// global rows [first, first + n) cut at block boundaries: f(shard, global_first, count)
+template <typename F>
+static int for_each_piece(const vrod_index* idx, uint64_t first, uint64_t n, F&& f) {
+    const uint64_t G = idx->shards.size();
+    uint64_t r = first;
+    const uint64_t end = first + n;
+    while (r < end) {
+        const uint64_t blk = r / kShardBlock;
+        const uint64_t m = std::min<uint64_t>(end - r, (blk + 1) * kShardBlock - r);
+        VROD_TRY(f((size_t)(blk % G), r, m));
+        r += m;
+    }
+    return VROD_OK;
+}
+static uint64_t local_row_of(const vrod_index* idx, uint64_t r) {
+    const uint64_t G = idx->shards.size();
+    return (r / (kShardBlock * G)) * kShardBlock + r % kShardBlock;
+}
+
+static int composite_add(vrod_index* idx, const float* rows, uint64_t n, bool synthetic, uint64_t seed, uint64_t first_row) {
+    const uint64_t count0 = idx->count;
+    int rc = for_each_piece(idx, count0, n, [&](size_t g, uint64_t r, uint64_t m) {
+        vrod_index* sh = idx->shards[g];
+        if (sh->count != local_row_of(idx, r)) return fail(VROD_ERR_INTERNAL, "shard %zu is out of step", g);
+        return index_add(sh, rows ? rows + (r - count0) * idx->dim : nullptr, m, synthetic, seed, first_row + (r - count0));
+    });
+    if (rc != VROD_OK) {
+        // a rejected piece (NaN/Inf) rolled itself back; drop the pieces already taken by other shards
+        for (size_t g = 0; g < idx->shards.size(); ++g) {
+            vrod_index* sh = idx->shards[g];
+            uint64_t want = 0;   // local rows of shard g among global rows [0, count0)
+            (void)for_each_piece(idx, 0, count0, [&](size_t gg, uint64_t, uint64_t m) { if (gg == g) want += m; return (int)VROD_OK; });
+            if (sh->count > want) {
+                (void)hipSetDevice(sh->device);
+                (void)hipMemsetAsync((char*)sh->corpus + want * sh->row_bytes(), 0, (sh->count - want) * sh->row_bytes(), sh->stream);
+                (void)hipMemsetAsync(sh->xnorm2 + want, 0, (sh->count - want) * sizeof(float), sh->stream);
+                (void)hipStreamSynchronize(sh->stream);
+                sh->count = want;
+            }
+        }
+        return rc;
+    }
+    idx->count = count0 + n;
+    return VROD_OK;
+}
+
+static int composite_get_rows(vrod_index* idx, uint64_t first, uint64_t n, float* out_rows) {
+    return for_each_piece(idx, first, n, [&](size_t g, uint64_t r, uint64_t m) {
+        return vrod_index_get_rows(idx->shards[g], local_row_of(idx, r), m, out_rows + (r - first) * idx->dim);
+    });
+}
+
+// queries: host pointer (from_host) or device pointer on shards[0]'s device; outputs likewise
+static int composite_search(vrod_index* idx, const float* queries, bool from_host, uint32_t nq, uint32_t k,
+                            uint64_t* out_ids, float* out_scores) {
+    const size_t G = idx->shards.size();
+    idx->stats = vrod_search_stats{};
+    idx->stats.nq = nq;
+    idx->stats.k = k;
+    if (!nq) return VROD_OK;
+    const size_t qbytes = (size_t)nq * idx->dim * 4, nk = (size_t)nq * k;
+    idx->sh_q.resize(G); idx->sh_ids.resize(G); idx->sh_scores.resize(G);
+    int rc = VROD_OK;
+    // enqueue on every device, then complete: the shards scan concurrently
+    for (size_t g = 0; g < G; ++g) {
+        vrod_index* sh = idx->shards[g];
+        if ((rc = set_device(sh)) != VROD_OK || (rc = idx->sh_q[g].ensure(qbytes)) != VROD_OK ||
+            (rc = idx->sh_ids[g].ensure(nk * 8)) != VROD_OK || (rc = idx->sh_scores[g].ensure(nk * 4)) != VROD_OK) break;
+        if (hipMemcpyAsync(idx->sh_q[g].p, queries, qbytes, from_host ? hipMemcpyHostToDevice : hipMemcpyDefault, sh->stream) != hipSuccess) {
+            rc = fail(VROD_ERR_HIP, "query upload to device %d failed", sh->device);
+            break;
+        }
+        sh->path = idx->path;
+        sh->profiling = idx->profiling;
+        rc = search_begin(sh, idx->sh_q[g].as<float>(), nq, k, idx->sh_ids[g].as<uint64_t>(), idx->sh_scores[g].as<float>());
+        if (rc != VROD_OK) break;
+    }
+    for (size_t g = 0; g < G; ++g) {
+        if (idx->shards[g]->n_pending() == 0) continue;   // not begun (an earlier shard failed to enqueue)
+        vrod_index* sh = idx->shards[g];
+        VROD_TRY(set_device(sh));
+        const int r = search_end(sh);     // every begun search is ended, whatever the others return
+        if (r != VROD_OK && rc == VROD_OK) rc = r;
+        const vrod_search_stats& st = sh->stats;
+        idx->stats.path = st.path; idx->stats.kprime = st.kprime;
+        idx->stats.scan_launches += st.scan_launches;
+        idx->stats.fallback_queries += st.fallback_queries;
+        idx->stats.scan_ms = std::max(idx->stats.scan_ms, st.scan_ms);
+        idx->stats.total_ms = std::max(idx->stats.total_ms, st.total_ms);
+        idx->stats.scan_bytes += st.scan_bytes; idx->stats.scan_flops += st.scan_flops;
+        idx->stats.max_fast_err = std::max(idx->stats.max_fast_err, st.max_fast_err);
+        idx->stats.eps_bound = std::max(idx->stats.eps_bound, st.eps_bound);
+    }
+    if (rc != VROD_OK) return rc;
+    // gather the per-shard lists on the first device (packed: ids | scores per shard), translate
+    // local rows to global ids, merge
+    vrod_index* s0 = idx->shards[0];
+    VROD_TRY(set_device(s0));
+    const size_t block = nk * 12;
+    VROD_TRY(idx->gather.ensure(G * block));
+    VROD_TRY(idx->out_ids.ensure(nk * 8));
+    VROD_TRY(idx->out_scores.ensure(nk * 4));
+    for (size_t g = 0; g < G; ++g) {
+        char* dst = (char*)idx->gather.p + g * block;
+        HIP_TRY(hipMemcpyPeerAsync(dst, s0->device, idx->sh_ids[g].p, idx->shards[g]->device, nk * 8, s0->stream));
+        HIP_TRY(hipMemcpyPeerAsync(dst + nk * 8, s0->device, idx->sh_scores[g].p, idx->shards[g]->device, nk * 4, s0->stream));
+    }
+    launch_shard_ids_to_global((uint64_t*)idx->gather.p, block / 8, (uint32_t)G, nk, kShardBlock, idx->id_offset, s0->stream);
+    launch_merge_topk(idx->metric, (const uint64_t*)idx->gather.p, (const float*)((const char*)idx->gather.p + nk * 8), block / 8, block / 4,
+                      (uint32_t)G, nq, k, idx->out_ids.as<uint64_t>(), idx->out_scores.as<float>(), s0->stream);
+    HIP_TRY(hipGetLastError());
+    const hipMemcpyKind kind = from_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIP_TRY(hipMemcpyAsync(out_ids, idx->out_ids.p, nk * 8, kind, s0->stream));
+    HIP_TRY(hipMemcpyAsync(out_scores, idx->out_scores.p, nk * 4, kind, s0->stream));
+    HIP_TRY(hipStreamSynchronize(s0->stream));
+    return VROD_OK;
+}
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -665,9 +795,22 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
     if (dtype != VROD_DTYPE_F32 && dtype != VROD_DTYPE_BF16) return fail(VROD_ERR_INVALID_ARG, "bad dtype %d", dtype);
     if (metric != VROD_METRIC_COSINE && metric != VROD_METRIC_L2) return fail(VROD_ERR_INVALID_ARG, "bad metric %d", metric);
     if (n_devices < 0 || (n_devices > 0 && !device_ids)) return fail(VROD_ERR_INVALID_ARG, "bad device list");
-    if (n_devices > 1)
-        return fail(VROD_ERR_UNSUPPORTED, "one handle drives one GPU in this build: create one handle per GPU "
-                                           "(vrod_index_set_id_offset) and merge with vrod_merge_topk_device");
+    if (n_devices > 1) {
+        if (n_devices > 64) return fail(VROD_ERR_INVALID_ARG, "at most 64 devices per handle");
+        vrod_index* c = new (std::nothrow) vrod_index();
+        if (!c) return fail(VROD_ERR_OUT_OF_MEMORY, "host allocation failed");
+        c->dim = dim; c->dtype = dtype; c->metric = metric;
+        for (int g = 0; g < n_devices; ++g) {
+            vrod_index* sh = nullptr;
+            const int rc = vrod_index_create(&sh, dim, dtype, metric, &device_ids[g], 1);
+            if (rc != VROD_OK) { vrod_index_destroy(c); return rc; }
+            c->shards.push_back(sh);
+        }
+        c->device = c->shards[0]->device;
+        c->ld = c->shards[0]->ld; c->esize = c->shards[0]->esize;
+        *out = c;
+        return VROD_OK;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(VROD_ERR_NO_DEVICE, "no HIP device visible: libvrod_hip has no CPU fallback");
@@ -702,6 +845,17 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
 
 int vrod_index_destroy(vrod_index* idx) {
     if (!idx) return VROD_OK;
+    if (idx->composite()) {
+        for (size_t g = 0; g < idx->shards.size(); ++g) {
+            (void)hipSetDevice(idx->shards[g]->device);
+            if (g < idx->sh_q.size()) { idx->sh_q[g].release(); idx->sh_ids[g].release(); idx->sh_scores[g].release(); }
+        }
+        (void)hipSetDevice(idx->device);
+        idx->gather.release(); idx->out_ids.release(); idx->out_scores.release(); idx->q_raw.release();
+        for (vrod_index* sh : idx->shards) vrod_index_destroy(sh);
+        delete idx;
+        return VROD_OK;
+    }
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     for (DevBuf* b : {&idx->raw_stage, &idx->nrm_ws, &idx->q_raw, &idx->q_lp, &idx->scores, &idx->keys_a,
@@ -725,6 +879,12 @@ int vrod_index_destroy(vrod_index* idx) {
 
 int vrod_index_reserve(vrod_index* idx, uint64_t n_rows) {
     if (!idx) return fail(VROD_ERR_INVALID_ARG, "idx is null");
+    if (idx->composite()) {
+        const uint64_t G = idx->shards.size();
+        const uint64_t per = (n_rows / (kShardBlock * G) + 1) * kShardBlock;   // whole blocks per shard
+        for (vrod_index* sh : idx->shards) VROD_TRY(vrod_index_reserve(sh, per));
+        return VROD_OK;
+    }
     VROD_TRY(require_idle(idx, "vrod_index_reserve"));
     VROD_TRY(set_device(idx));
     return index_reserve(idx, n_rows);
@@ -732,12 +892,14 @@ int vrod_index_reserve(vrod_index* idx, uint64_t n_rows) {
 
 int vrod_index_add(vrod_index* idx, const float* rows, uint64_t n) {
     if (!idx || (!rows && n)) return fail(VROD_ERR_INVALID_ARG, "null argument");
+    if (idx->composite()) return composite_add(idx, rows, n, false, 0, 0);
     VROD_TRY(require_idle(idx, "vrod_index_add"));
     return index_add(idx, rows, n, false, 0, 0);
 }
 
 int vrod_index_add_synthetic(vrod_index* idx, uint64_t seed, uint64_t first_row, uint64_t n) {
     if (!idx) return fail(VROD_ERR_INVALID_ARG, "idx is null");
+    if (idx->composite()) return composite_add(idx, nullptr, n, true, seed, first_row);
     VROD_TRY(require_idle(idx, "vrod_index_add_synthetic"));
     return index_add(idx, nullptr, n, true, seed, first_row);
 }
@@ -758,6 +920,7 @@ int vrod_index_get_rows(vrod_index* idx, uint64_t first, uint64_t n, float* out_
     if (!idx || (!out_rows && n)) return fail(VROD_ERR_INVALID_ARG, "null argument");
     if (first + n > idx->count) return fail(VROD_ERR_INVALID_ARG, "rows [%llu, %llu) out of range", (unsigned long long)first, (unsigned long long)(first + n));
     if (!n) return VROD_OK;
+    if (idx->composite()) return composite_get_rows(idx, first, n, out_rows);
     VROD_TRY(require_idle(idx, "vrod_index_get_rows"));
     VROD_TRY(set_device(idx));
     VROD_TRY(idx->raw_stage.ensure(n * idx->dim * 4));
@@ -778,6 +941,10 @@ static int check_search_args(vrod_index* idx, const void* q, uint32_t nq, uint32
 int vrod_search_device(vrod_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
                        uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, d_queries, nq, k, d_out_ids, d_out_scores));
+    if (idx->composite()) {   // pointers on the first device of the handle
+        if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        return composite_search(idx, d_queries, false, nq, k, d_out_ids, d_out_scores);
+    }
     VROD_TRY(require_idle(idx, "vrod_search_device"));
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));   // the caller's inputs are ready
@@ -787,6 +954,7 @@ int vrod_search_device(vrod_index* idx, const float* d_queries, uint32_t nq, uin
 int vrod_search_begin_device(vrod_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
                              uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, d_queries, nq, k, d_out_ids, d_out_scores));
+    if (idx->composite()) return fail(VROD_ERR_UNSUPPORTED, "the pipelined form is per device: a multi-device handle searches all its devices in one call");
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));
     return search_begin(idx, d_queries, nq, k, d_out_ids, d_out_scores);
@@ -795,6 +963,7 @@ int vrod_search_begin_device(vrod_index* idx, const float* d_queries, uint32_t n
 int vrod_search_begin_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t first_row, uint32_t nq,
                                        uint32_t k, uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, (void*)1, nq, k, d_out_ids, d_out_scores));
+    if (idx->composite()) return fail(VROD_ERR_UNSUPPORTED, "the pipelined form is per device: a multi-device handle searches all its devices in one call");
     if (idx->n_pending() >= 2) return fail(VROD_ERR_INVALID_ARG, "two searches are already pending: call vrod_search_end first");
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));
@@ -807,6 +976,7 @@ int vrod_search_begin_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t 
 
 int vrod_search_end(vrod_index* idx) {
     if (!idx) return fail(VROD_ERR_INVALID_ARG, "idx is null");
+    if (idx->composite()) return fail(VROD_ERR_INVALID_ARG, "no search is pending");
     VROD_TRY(set_device(idx));
     return search_end(idx);
 }
@@ -820,6 +990,15 @@ int vrod_search_pending(const vrod_index* idx, uint32_t* out_pending) {
 int vrod_search_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t first_row, uint32_t nq,
                                  uint32_t k, uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, (void*)1, nq, k, d_out_ids, d_out_scores));
+    if (idx->composite()) {
+        vrod_index* s0 = idx->shards[0];
+        VROD_TRY(set_device(s0));
+        if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        VROD_TRY(idx->q_raw.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
+        launch_synth_rows(seed, first_row, nq, idx->dim, idx->q_raw.as<float>(), s0->stream);
+        HIP_TRY(hipStreamSynchronize(s0->stream));
+        return composite_search(idx, idx->q_raw.as<float>(), false, nq, k, d_out_ids, d_out_scores);
+    }
     VROD_TRY(require_idle(idx, "vrod_search_synthetic_device"));
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));
@@ -832,6 +1011,7 @@ int vrod_search(vrod_index* idx, const float* queries, uint32_t nq, uint32_t k, 
                 float* out_scores) {
     VROD_TRY(check_search_args(idx, queries, nq, k, out_ids, out_scores));
     if (!nq) return VROD_OK;
+    if (idx->composite()) return composite_search(idx, queries, true, nq, k, out_ids, out_scores);
     VROD_TRY(require_idle(idx, "vrod_search"));
     VROD_TRY(set_device(idx));
     VROD_TRY(idx->q_raw.ensure((size_t)nq * idx->dim * 4));
@@ -876,7 +1056,7 @@ int vrod_merge_topk_packed_device(int device, int metric, const void* d_packed, 
 
 int vrod_index_set_path(vrod_index* idx, int path) {
     if (!idx || path < VROD_PATH_AUTO || path > VROD_PATH_EXACT) return fail(VROD_ERR_INVALID_ARG, "bad path");
-    VROD_TRY(require_idle(idx, "vrod_index_set_path"));
+    if (!idx->composite()) VROD_TRY(require_idle(idx, "vrod_index_set_path"));
     idx->path = path;
     return VROD_OK;
 }

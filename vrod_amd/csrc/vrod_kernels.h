@@ -31,6 +31,8 @@ void launch_prep_queries(const float* d_in, uint32_t nq, uint32_t nq_pad, uint32
                          uint32_t* d_max_bits, const QueryInit& init, hipStream_t s);
 // tail of a search: status[nq] followed by {bad flag, max |q|^2 bits, max err bits, max |x|^2 bits}
 // gathered into one contiguous block so that the host needs ONE device-to-host copy
+void launch_shard_ids_to_global(uint64_t* d_ids, uint64_t list_stride, uint32_t n_lists, uint64_t per_list,
+                                uint64_t block_rows, uint64_t id_offset, hipStream_t s);
 void launch_gather_readback(const uint32_t* d_status, uint32_t nq, uint32_t* d_flags3, const uint32_t* d_max_xn2,
                             uint32_t* d_out, hipStream_t s);
 void launch_row_fastnorm(const void* d_rows, int dtype, uint64_t n, uint32_t ld, float* d_xn2,

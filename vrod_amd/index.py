@@ -35,15 +35,18 @@ def _enum(v, table, what):
 class Index:
     """One shard of a brute-force index on one MI355X."""
 
-    def __init__(self, dim: int, dtype="f32", metric="cosine", device: int = 0):
+    def __init__(self, dim: int, dtype="f32", metric="cosine", device: int = 0, devices=None):
+        """`devices` (a list of device ids, repeats allowed) makes ONE handle that deals its rows to
+        several GPUs and searches them all per call (vrod_index_create with n_devices > 1)."""
         self._L = _lib.load()
         self._h = C.c_void_p()
         self.dim = int(dim)
         self.dtype = _enum(dtype, _DTYPES, "dtype")
         self.metric = _enum(metric, _METRICS, "metric")
-        self.device = int(device)
-        dev = (C.c_int * 1)(self.device)
-        check(self._L.vrod_index_create(C.byref(self._h), self.dim, self.dtype, self.metric, dev, 1))
+        ids = [int(d) for d in devices] if devices is not None else [int(device)]
+        self.device = ids[0]
+        dev = (C.c_int * len(ids))(*ids)
+        check(self._L.vrod_index_create(C.byref(self._h), self.dim, self.dtype, self.metric, dev, len(ids)))
 
     # -- lifecycle
     def close(self):
