@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VROD = os.path.join(ROOT, "vrod_amd", "vrod")
 
 
-def run(*args, cwd=None):
-    return subprocess.run([VROD, *args], capture_output=True, text=True, cwd=cwd)
+def run(*args, cwd=None, env=None):
+    return subprocess.run([VROD, *args], capture_output=True, text=True, cwd=cwd, env=env)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -112,3 +112,31 @@ def test_bulkinsert_and_searchsimilar_match_oracle(tmp_path, oracle):
     qf.write_text("\n".join(",".join(repr(float(v)) for v in rq[i]) + ";ignored" for i in range(nq)) + "\n")
     r = run("-d", db, "-c", "alice", "-e", "SEARCHSIMILAR", "-a", f"k=3;@{qf}")
     assert r.returncode == 0 and len(r.stdout.strip().split("\n")) == nq * 3
+
+
+@pytest.mark.gpu
+def test_searchsimilar_over_a_multi_device_collection(tmp_path, oracle):
+    """VROD_DEVICES=0,0: the collection is one multi-device handle (two shards on device 0 here);
+    SEARCHSIMILAR prints the same ids and scores as the single-device run."""
+    n, dim, nq, k = 70000, 8, 2, 5          # 70000 rows: both shards hold rows
+    raw = oracle.synth_rows(3, 0, n, dim, threads=8)
+    rq = oracle.synth_rows(4, 0, nq, dim)
+    f32 = tmp_path / "rows.f32"
+    raw.tofile(f32)
+    assert run("-i", str(tmp_path), "-n", "d").returncode == 0
+    db = str(tmp_path / "d")
+    env = dict(os.environ, VROD_DEVICES="0,0")
+    assert run("-d", db, "-e", "CREATE", "-a", "c metric=l2 dtype=f32", env=env).returncode == 0
+    r = run("-d", db, "-c", "c", "-e", "BULKINSERT", "-a", f"{f32}:{dim}", env=env)
+    assert r.returncode == 0, r.stderr
+    qarg = f"k={k};" + ";".join(",".join(repr(float(v)) for v in rq[i]) for i in range(nq))
+    outs = []
+    for e in (env, None):
+        r = run("-d", db, "-c", "c", "-e", "SEARCHSIMILAR", "-a", qarg, env=e)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1]
+    rows = [l.split("\t") for l in outs[0].strip().split("\n")]
+    ids = np.array([int(x[2]) for x in rows], dtype=np.uint64).reshape(nq, k)
+    oi, _ = oracle.search(raw, rq, k, 0, 1)
+    assert np.array_equal(ids, oi)

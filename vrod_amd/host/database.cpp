@@ -11,6 +11,7 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 
@@ -85,10 +86,27 @@ void Collection::load_config() {
     }
 }
 
+// VROD_DEVICES=0,1,2,...: the GPUs a collection is sharded over (one multi-device handle,
+// include/vrod.h); unset = the first device.
+static int create_index(vrod_index** out, uint32_t dim, int dtype, int metric) {
+    std::vector<int> devs;
+    if (const char* e = std::getenv("VROD_DEVICES")) {
+        std::string tok;
+        for (const char* p = e;; ++p) {
+            if (*p == ',' || *p == '\0') {
+                if (!tok.empty()) devs.push_back(std::atoi(tok.c_str()));
+                tok.clear();
+                if (*p == '\0') break;
+            } else tok.push_back(*p);
+        }
+    }
+    return vrod_index_create(out, dim, dtype, metric, devs.empty() ? nullptr : devs.data(), (int)devs.size());
+}
+
 void Collection::ensure_resident() {
     if (index_) return;
     if (cfg_.dim == 0) throw IoError(IoError::InvalidData, "collection '" + name_ + "' is empty");
-    check(vrod_index_create(&index_, cfg_.dim, cfg_.dtype, cfg_.metric, nullptr, 0), "vrod_index_create");
+    check(create_index(&index_, cfg_.dim, cfg_.dtype, cfg_.metric), "vrod_index_create");
     if (cfg_.count == 0) return;
     check(vrod_index_reserve(index_, cfg_.count), "vrod_index_reserve");
     std::ifstream f(join(dir_, "vr_vectors"), std::ios::binary);
@@ -114,7 +132,7 @@ void Collection::insert(const std::vector<float>& rows, uint32_t dim, const std:
                                                 std::to_string(cfg_.dim));
     // device first (it validates NaN/Inf), then disk
     if (index_ || cfg_.count > 0) ensure_resident();
-    if (!index_) check(vrod_index_create(&index_, cfg_.dim, cfg_.dtype, cfg_.metric, nullptr, 0), "vrod_index_create");
+    if (!index_) check(create_index(&index_, cfg_.dim, cfg_.dtype, cfg_.metric), "vrod_index_create");
     check(vrod_index_add(index_, rows.data(), n), "vrod_index_add");
     {
         std::ofstream f(join(dir_, "vr_vectors"), std::ios::binary | std::ios::app);
