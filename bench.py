@@ -52,8 +52,8 @@ ME = {"cosine": 0, "l2": 1}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=0, help="override total corpus rows (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
