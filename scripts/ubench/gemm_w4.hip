@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void gemm_w4(const Args a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64() - clk0; a.clk[1] = wall_clock64() - wall0; }
+    if (tid == 0) { a.clk[2 + 2 * blockIdx.x] = wall0; a.clk[3 + 2 * blockIdx.x] = wall_clock64(); }
     float* o = a.out + ((uint64_t)blockIdx.x * 256 + tid) * 8;
 #pragma unroll
     for (int n = 0; n < 8; ++n) o[n] = best[n];
@@ -327,7 +328,7 @@ int main(int argc, char** argv) {
     fill_kernel<<<256, 256>>>(d_q, (uint64_t)nq * ld, 2);
     hipMemset(d_out, 0, 256 * 256 * 8 * 4);
     const uint32_t flags = argc > 3 ? atoi(argv[3]) : 0;
-    unsigned long long* d_clk; hipMalloc(&d_clk, 16);
+    unsigned long long* d_clk; hipMalloc(&d_clk, 16 + 256 * 16);
     Args a{(const char*)d_c, (const char*)d_q, d_out, ld * 2, rows / 256, nq / 256, flags, d_clk};
     double ms = 0;
     switch (var) {
@@ -347,7 +348,15 @@ int main(int argc, char** argv) {
         default: printf("bad variant\n"); return 1;
     }
     const double tf = 2.0 * rows * nq * dim / (ms * 1e-3) / 1e12;
-    unsigned long long hclk[2]; hipMemcpy(hclk, d_clk, 16, hipMemcpyDeviceToHost);
+    unsigned long long hclk[2 + 512]; hipMemcpy(hclk, d_clk, 16 + 256 * 16, hipMemcpyDeviceToHost);
+    {   // per-work-group start/end (100 MHz ticks): spread of the static partition
+        unsigned long long t0 = ~0ull, t1 = 0; double sum = 0, mx = 0, mn = 1e30; double xs[8] = {0};
+        for (int b = 0; b < 256; ++b) { if (hclk[2 + 2 * b] < t0) t0 = hclk[2 + 2 * b]; if (hclk[3 + 2 * b] > t1) t1 = hclk[3 + 2 * b]; }
+        for (int b = 0; b < 256; ++b) { const double d = (double)(hclk[3 + 2 * b] - hclk[2 + 2 * b]) * 0.01; sum += d; if (d > mx) mx = d; if (d < mn) mn = d; xs[b & 7] += d / 32; }
+        printf("  work-group busy time us: min %.1f mean %.1f max %.1f; kernel span %.1f; per XCD mean:", mn, sum / 256, mx, (double)(t1 - t0) * 0.01);
+        for (int x = 0; x < 8; ++x) printf(" %.0f", xs[x]);
+        printf("\n");
+    }
     const double ghz = (double)hclk[0] / (double)hclk[1] * 0.1;
     printf("variant %2d flags %u rows %u: %.3f ms  %7.1f TFLOP/s  sclk %.2f GHz  -> %.1f %% of the MFMA rate at that clock\n", var, flags, rows, ms, tf, ghz,
            100.0 * tf / (2500.0 * ghz / 2.4));

@@ -313,25 +313,25 @@ static int select_chain(vrod_index* idx, const float* d_scores, uint64_t score_l
 struct StagePlan { uint32_t S, j; std::vector<uint64_t> bounds; };
 static StagePlan plan_stages(uint64_t N, uint32_t kp, uint32_t cap, uint32_t max_sample_rows) {
     StagePlan p;
-    // growth per filtered stage: a stage over g times the rows seen so far appends about g*k' rows
-    // per query; keep that under a third of the list capacity, and under 32 so that lists stay short
-    const double gmax = (double)std::max<uint64_t>(2, std::min<uint64_t>(32, cap / (3ull * kp)));
-    // sample: at most one round of work-groups (one 256-row tile per work-group of the dense launch)
-    uint64_t S = std::min<uint64_t>(N / 64, max_sample_rows);
+    // Growth per filtered stage.  A stage over rows (b, g*b] runs against the k'-th best of the
+    // first b rows, so about k'*(g-1) rows per query beat its threshold: that must stay well under
+    // the list capacity, and -- measured -- appends are not free: the first stage after the
+    // 16K-row sample appends one row in 630 per query (~100 per 256x256 tile) and runs at 1.9 us
+    // per 1000 rows against 1.3 once appends are rare.  The extra time of a stage is ~ (g-1), the
+    // number of stages ~ 1/ln g, each costing a launch ramp and a compaction (~40 us): the total is
+    // flat between g = 4 and 8 and twice as large at g = 25 (two stages at 10M rows: tried,
+    // +0.25 ms per batch).
+    const uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(8, cap / (3ull * kp)));
+    // sample: N/g^2 rows, at most one round of work-groups (one 256-row tile per work-group of
+    // the dense launch)
+    uint64_t S = std::min<uint64_t>(N / (g * g), max_sample_rows);
     S = std::max<uint64_t>(S, std::min<uint64_t>(N, std::max<uint64_t>(4ull * kp, kRowTile)));
     S = std::min<uint64_t>(round_up(S, kRowTile), N);
     p.S = (uint32_t)S;
     p.j = (uint32_t)std::min<uint64_t>(kp, S);
-    // fewest stages whose common growth factor fits: g = (N/S)^(1/L) <= gmax
-    const double ratio = (double)N / (double)S;
-    uint32_t L = 1;
-    while (std::pow(ratio, 1.0 / L) > gmax && L < 16) ++L;
-    const double g = std::pow(ratio, 1.0 / L);
-    double b = (double)S;
-    for (uint32_t i = 1; i < L; ++i) {
-        b *= g;
-        const uint64_t bi = (uint64_t)b / kRowTile * kRowTile;
-        if (bi > (p.bounds.empty() ? 0 : p.bounds.back()) && bi < N) p.bounds.push_back(bi);
+    for (uint64_t b = S * g; b < N; b *= g) {
+        if (N - b < b / 2) break;                    // the tail would be a sliver: fold it in
+        p.bounds.push_back(b / kRowTile * kRowTile);
     }
     p.bounds.push_back(N);
     return p;
