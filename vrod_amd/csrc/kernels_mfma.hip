@@ -60,6 +60,7 @@ constexpr int kLdsThr = kLdsTotal;                // [256] f32
 constexpr int kLdsQn2 = kLdsThr + 1024;           // [256] f32
 constexpr int kLdsXn2 = kLdsQn2 + 1024;           // [2][256] f32, slot = tile parity
 constexpr int kLdsTotalW4 = kLdsXn2 + 2048;
+constexpr int kLogCapW4 = kLogCap / 4;            // log entries per wave (4-wave kernel: wave-private segments)
 
 // raw s_barrier (no vmcnt drain) fenced for the compiler only: memory operations may not be
 // moved across it, nothing is emitted for the fences
@@ -683,12 +684,32 @@ __device__ __forceinline__ f32x4 w4_read_acc() {
     return v;
 }
 
+// Drain the four wave-private log segments (counts in log_cnt[4..7]) into the per-query lists.
+// Called by ALL threads at the same program point, after a barrier that follows every wave's
+// appends; the caller's waves reset their register counters.
+__device__ __forceinline__ void flush_log_w4(const MfmaKernelArgs& a, const uint2* log, uint32_t* log_cnt, uint32_t qb,
+                                             uint32_t rel_base, int tid) {
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t n = log_cnt[4 + w] < (uint32_t)kLogCapW4 ? log_cnt[4 + w] : (uint32_t)kLogCapW4;
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint2 e = log[w * kLogCapW4 + i];
+            global_append(a, qb * kBN + (e.y >> 24), e.x, rel_base + (e.y & 0xFFFFFFu));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { lds_zero3(log_cnt + 3); lds_zero3(log_cnt + 5); }
+    __syncthreads();
+}
+
 // The fused filter of the 4-wave kernel: the wave's 128 x 128 scores (in a[0:255]) against the 8
 // per-lane thresholds.  row_w = first row of the lane's 4-row group in tile m = 0.
 template <int METRIC>
 __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const float* thr_l, const float* qn2_l, const float* xn_l,
                                                uint32_t row_w, uint32_t ql0, uint32_t qb, uint32_t rel_base,
-                                               uint2* log, uint32_t* log_cnt) {
+                                               uint2* log /* this wave's segment */, uint32_t* log_cnt, int wave, uint32_t& wlog) {
+    const uint32_t wlog_in = wlog;
     // thr_l / qn2_l: the work-group's per-query values in LDS; xn_l: this lane's 4-row group of the
     // tile's row norms in LDS (m = 0), 16 floats apart per m
     float thr[8], qn2[8];
@@ -698,7 +719,6 @@ __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const fl
         qn2[n] = METRIC == M_L2 ? qn2_l[ql0 + n * 16] : 0.0f;
     }
     const uint32_t lds_log_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log;
-    const uint32_t lds_cnt_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log_cnt;
     // the last MFMAs are still in the pipe: an accumulator may be read 4 passes + 2 states later
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     float best[8];
@@ -744,22 +764,32 @@ __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const fl
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t row = row_w + m * 16 + r;
-                    if (better<METRIC>(sc[r], thr[n]) && row >= a.row_lo && row < a.row_end) {
-                        uint32_t pos;   // LDS log append in asm (see filter_tile)
-                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=v"(pos) : "v"(lds_cnt_addr), "v"(1u) : "memory");
-                        if (pos < (uint32_t)kLogCap) {
+                    const bool hitr = better<METRIC>(sc[r], thr[n]) && row >= a.row_lo && row < a.row_end;
+                    // the wave owns a quarter of the log and counts its entries in a register: a
+                    // ballot and a lane prefix give every hit its slot -- no LDS atomic, no wait.
+                    // (The write stays in asm: as a compiler-visible LDS store it would be preceded
+                    // by s_waitcnt vmcnt(0), see filter_tile.)
+                    const unsigned long long hm = __ballot(hitr);
+                    if (hm == 0ull) continue;
+                    const uint32_t pos = wlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                    if (hitr) {
+                        if (pos < (uint32_t)kLogCapW4) {
                             const uint64_t e = ((uint64_t)((ql << 24) | (row - rel_base)) << 32) | __float_as_uint(sc[r]);
                             asm volatile("ds_write_b64 %0, %1" :: "v"(lds_log_addr + pos * 8u), "v"(e) : "memory");
-                            if (pos >= (uint32_t)(kLogCap / 2))
-                                asm volatile("ds_write_b32 %0, %1" :: "v"(lds_cnt_addr + 12u), "v"(1u) : "memory");
                         } else {
                             global_append(a, qb * kBN + ql, __float_as_uint(sc[r]), row);
                         }
                     }
+                    wlog += (uint32_t)__builtin_popcountll(hm);
                 }
             });
         });
+    }
+    // publish the wave's count for the flush; past half of the segment: ask for one
+    if (wlog != wlog_in) {
+        const uint32_t cnt_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log_cnt;
+        asm volatile("ds_write_b32 %0, %1" :: "v"(cnt_addr + 16u + 4u * (uint32_t)wave), "v"(wlog) : "memory");
+        if (wlog >= (uint32_t)(kLogCapW4 / 2)) asm volatile("ds_write_b32 %0, %1" :: "v"(cnt_addr + 12u), "v"(1u) : "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -804,7 +834,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
     const uint32_t t1 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * (strip + 1) / a.nstrips);
     if (t0 >= t1) return;
 
-    if (tid == 0) { lds_zero3(log_cnt); lds_zero3(log_cnt + 1); }
+    if (tid == 0) { lds_zero3(log_cnt); lds_zero3(log_cnt + 3); lds_zero3(log_cnt + 5); }
     __syncthreads();
 
     const uint32_t KT = a.ld_bytes >> 7;
@@ -917,15 +947,15 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
                 w4_dense_store_tile<METRIC>(a, qn2_l, wc * 128 + fr, tile * kBM + wr * 128 + fg * 4, qb * kBN + wc * 128 + fr); \
             else                                                                                   \
                 w4_filter_tile<METRIC>(a, thr_l, qn2_l, xn_l + (tile & 1) * 256 + wr * 128 + fg * 4,        \
-                                       tile * kBM + wr * 128 + fg * 4, wc * 128 + fr, qb, rel_base, log, log_cnt); \
+                                       tile * kBM + wr * 128 + fg * 4, wc * 128 + fr, qb, rel_base,          \
+                                       log + wave * kLogCapW4, log_cnt, wave, wlog);                        \
             kt = 0; ++tile;                                                                        \
         } else ++kt;                                                                               \
         asm volatile(W4_VMWAIT ::: "memory");                                                      \
         VROD_BARRIER();                                                                            \
         if (!DENSE && last && log_cnt[3] != 0u) {   /* every wave's appends are behind the barrier */ \
-            flush_log(a, log, log_cnt, qb, rel_base, tid);                                         \
-            if (tid == 0) log_cnt[3] = 0u;                                                         \
-            __syncthreads();                                                                       \
+            flush_log_w4(a, log, log_cnt, qb, rel_base, tid);                                      \
+            wlog = 0u;                                                                             \
         }                                                                                          \
         ++it;                                                                                      \
     }
@@ -943,6 +973,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         VROD_BARRIER();   // every wave holds its first fragments: buffer 0's A_m0 / B_n0 may be restaged
 
         uint32_t it = 0, kt = 0, tile = t0;
+        uint32_t wlog = 0u;   // entries in this wave's log segment (wave-uniform)
         while (it < total_it) {
             W4_ITER(FBx, FBy, W4_LDQ0x, W4_LDQ3x)
             if (it >= total_it) break;
@@ -968,11 +999,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #undef W4_LDP_B
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if constexpr (!DENSE) {
-            flush_log(a, log, log_cnt, qb, rel_base, tid);
-            if (tid == 0) log_cnt[3] = 0u;
-            __syncthreads();
-        }
+        if constexpr (!DENSE) flush_log_w4(a, log, log_cnt, qb, rel_base, tid);
     }
 }
 
