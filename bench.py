@@ -187,15 +187,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VROD_BENCH_BACKEND=gloo: rehearsal of the N>1 control flow on a box with fewer GPUs than
+    # ranks (ranks share devices, the exchange is staged through the host) -- never a measurement
+    backend = os.environ.get("VROD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # VROD_BENCH_FORCE_COLLECTIVE=1: run the all-gather + merge even with one rank (rehearsal of
     # the N>1 code path on a 1-GPU box; the exchange is then part of the timed step)
     force_coll = os.environ.get("VROD_BENCH_FORCE_COLLECTIVE") == "1"
     if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import vrod_amd as va
     va.load()  # raises without the HIP library: there is no fallback path
@@ -204,7 +211,7 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     n_total = args.rows or wl["n"]
     lo, hi = shard_range(n_total, rank, world)
-    ix = va.Index(wl["dim"], wl["dtype"], wl["metric"], device=local_rank)
+    ix = va.Index(wl["dim"], wl["dtype"], wl["metric"], device=dev_index)
     ix.add_synthetic(CORPUS_SEED, lo, hi - lo)   # shard rows [lo, hi) of the synthetic stream, generated in HBM
     ix.set_id_offset(lo)
     ix.set_profiling(True)
@@ -212,7 +219,7 @@ def main():
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1 or force_coll:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
             torch.cuda.synchronize(dev)
 
     coll = world > 1 or force_coll
@@ -223,11 +230,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # per-rank kernel stats: report the slowest rank's scan time, the sum of flops
-        ks = torch.tensor([acc["scan_ms"], acc["scan_flops"], acc["scan_bytes"], float(acc["fallback"])], dtype=torch.float64, device=dev)
+        ks = torch.tensor([acc["scan_ms"], acc["scan_flops"], acc["scan_bytes"], float(acc["fallback"])], dtype=torch.float64, device=rdev)
         kmax = ks.clone(); dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         ksum = ks.clone(); dist.all_reduce(ksum, op=dist.ReduceOp.SUM)
         fallback_total = int(ksum[3].item())
@@ -279,6 +287,14 @@ def main():
             "exactness": {"certificate_fallback_queries": fallback_total, "max_fast_err": acc["max_err"], "eps_bound": acc["eps"],
                           "note": "ids and score bits equal the CPU oracle by construction (canonical re-score + certificate)"},
         }
+        if os.environ.get("VROD_BENCH_VERIFY") == "1":
+            # rehearsal check: the merged result of the last timed batch equals a one-device search of all rows
+            with va.Index(wl["dim"], wl["dtype"], wl["metric"], device=dev_index) as fx:
+                fx.add_synthetic(CORPUS_SEED, 0, n_total)
+                vi = torch.empty((nq, wl["k"]), dtype=torch.int64, device=dev)
+                vs = torch.empty((nq, wl["k"]), dtype=torch.float32, device=dev)
+                fx.search_synthetic_device(QUERY_SEED, (args.warmup + args.steps - 1) * nq, nq, wl["k"], vi, vs)
+                out["verify_merged_equals_single_device"] = bool(torch.equal(vi, final[0]) and torch.equal(vs.view(torch.int32), final[1].view(torch.int32)))
         if world == 1 and not args.no_cpu_baseline:
             cb, recall, bit_exact, rs = cpu_baseline(wl, va, torch, dev, n_total)
             out["cpu_baseline"] = cb
@@ -289,7 +305,7 @@ def main():
             # the north_star's second roofline: the memory-bound 1-query scan (configs[1])
             ix.close()
             w2 = WORKLOADS["cfg2"]
-            hx = va.Index(w2["dim"], w2["dtype"], w2["metric"], device=local_rank)
+            hx = va.Index(w2["dim"], w2["dtype"], w2["metric"], device=dev_index)
             hx.add_synthetic(CORPUS_SEED, 0, w2["n"])
             hx.set_profiling(True)
             run_steps(hx, w2, 3, 0, 1, 0, dist, va, torch, dev)
@@ -310,7 +326,7 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if world > 1 or force_coll:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -51,6 +51,14 @@ def all_gather_packed(dist, packed, out=None):
     world = dist.get_world_size()
     if out is None:
         out = torch.empty(world * packed.numel(), dtype=torch.uint8, device=packed.device)
+    if packed.is_cuda and dist.get_backend() != "nccl":
+        # rehearsal backends (gloo): stage through the host
+        torch.cuda.current_stream(packed.device).synchronize()
+        h_in = packed.cpu()
+        h_out = torch.empty(world * packed.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(h_out, h_in)
+        out.copy_(h_out)
+        return out
     dist.all_gather_into_tensor(out, packed)
     return out
 
