@@ -95,6 +95,12 @@ struct Pending {
     uint64_t N = 0;
     uint64_t* out_ids = nullptr;
     float* out_scores = nullptr;
+    // Each slot has its own stream and its own workspaces, so the tail of search s (compaction,
+    // re-score, certificate, read-back) can run beside the head -- and, on the stream path, the
+    // scan -- of search s+1.  Only the corpus (read-only during a search) is shared.
+    hipStream_t stream = nullptr;
+    uint32_t* flags = nullptr;     // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits, [64..] pacing counters
+    DevBuf q_raw, q_lp, scores, keys_a, keys_b, lists, small, hist, cand_rows, cand_fast, cand_canon;
     DevBuf q_f32;                  // prepared queries (the exact path re-reads them)
     uint32_t* h_readback = nullptr;   // pinned host block: status[nq] + 4 scalars, one D2H per search
     size_t h_readback_words = 0;
@@ -122,9 +128,8 @@ struct vrod_index {
     vrod_search_stats stats{};
 
     // workspaces
-    DevBuf raw_stage, nrm_ws, q_raw, q_lp, scores, keys_a, keys_b, lists, small, hist;
-    DevBuf cand_rows, cand_fast, cand_canon, out_ids, out_scores;
-    uint32_t* flags = nullptr;  // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits
+    DevBuf raw_stage, nrm_ws, out_ids, out_scores;
+    uint32_t* flags = nullptr;  // [0] bad-value flag of the insert path; [8] max squared row norm
     Pending slot[2];
     uint32_t n_begun = 0, n_ended = 0;   // searches enqueued / completed: slot = counter & 1
     hipEvent_t caller_ev = nullptr;      // orders the caller's stream before ours
@@ -246,7 +251,7 @@ struct Timer {
             if (hipEventCreate(&e) != hipSuccess) return 0;
             P.ev.push_back(e);
         }
-        (void)hipEventRecord(P.ev[P.ev_used], idx->stream);
+        (void)hipEventRecord(P.ev[P.ev_used], P.stream);
         return P.ev_used++;
     }
     // two fresh events for the next scan launch (attached to the dispatch, not recorded as markers)
@@ -279,21 +284,21 @@ static uint32_t choose_kp(uint64_t count, uint32_t k) {
 
 // select chain over fast (or canonical) scores of `nq` queries -> keys of <= kSelectChunk per query
 // returns pointer/ld/n of the final key set through out params.
-static int select_chain(vrod_index* idx, const float* d_scores, uint64_t score_ld, uint64_t n, int nq,
+static int select_chain(vrod_index* idx, Pending& P, const float* d_scores, uint64_t score_ld, uint64_t n, int nq,
                         uint32_t kp, const uint64_t** out_keys, uint64_t* out_ld, uint64_t* out_n) {
     const uint64_t nch0 = (n + kSelectChunk - 1) / kSelectChunk;
     const uint64_t ld_a = nch0 * kp;
-    VROD_TRY(idx->keys_a.ensure((size_t)nq * ld_a * 8));
-    uint64_t cur_n = launch_select_from_scores(d_scores, score_ld, n, nq, idx->metric, kp, idx->keys_a.as<uint64_t>(), ld_a, idx->stream);
-    const uint64_t* cur = idx->keys_a.as<uint64_t>();
+    VROD_TRY(P.keys_a.ensure((size_t)nq * ld_a * 8));
+    uint64_t cur_n = launch_select_from_scores(d_scores, score_ld, n, nq, idx->metric, kp, P.keys_a.as<uint64_t>(), ld_a, P.stream);
+    const uint64_t* cur = P.keys_a.as<uint64_t>();
     uint64_t cur_ld = ld_a;
     bool a_is_cur = true;
     while (cur_n > kSelectChunk) {
         const uint64_t nch = (cur_n + kSelectChunk - 1) / kSelectChunk;
         const uint64_t nld = nch * kp;
-        DevBuf& dst = a_is_cur ? idx->keys_b : idx->keys_a;
+        DevBuf& dst = a_is_cur ? P.keys_b : P.keys_a;
         VROD_TRY(dst.ensure((size_t)nq * nld * 8));
-        cur_n = launch_select_from_keys(cur, cur_ld, cur_n, nq, kp, dst.as<uint64_t>(), nld, idx->stream);
+        cur_n = launch_select_from_keys(cur, cur_ld, cur_n, nq, kp, dst.as<uint64_t>(), nld, P.stream);
         cur = dst.as<uint64_t>();
         cur_ld = nld;
         a_is_cur = !a_is_cur;
@@ -349,7 +354,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     P.trivial = true;
     P.ev_used = 0; P.t0 = P.t1 = 0; P.scan_pairs.clear();
     if (!nq) return VROD_OK;
-    hipStream_t s = idx->stream;
+    hipStream_t s = P.stream;
     Timer tm(idx, P);
     P.t0 = tm.mark();
 
@@ -387,11 +392,11 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     VROD_TRY(P.q_f32.ensure((size_t)nq_pad * idx->ld * 4));
     void* q_lp = nullptr;
     if (idx->dtype == VROD_DTYPE_BF16) {
-        VROD_TRY(idx->q_lp.ensure((size_t)nq_pad * idx->ld * 2));
-        q_lp = idx->q_lp.p;
+        VROD_TRY(P.q_lp.ensure((size_t)nq_pad * idx->ld * 2));
+        q_lp = P.q_lp.p;
     }
-    VROD_TRY(idx->small.ensure((size_t)nq_pad * 4 * 5 + 64));  // qnorm2 | T | thr | status | readback
-    float* d_qn2 = idx->small.as<float>();
+    VROD_TRY(P.small.ensure((size_t)nq_pad * 4 * 5 + 64));  // qnorm2 | T | thr | status | readback
+    float* d_qn2 = P.small.as<float>();
     float* d_T = d_qn2 + nq_pad;
     float* d_thr = d_T + nq_pad;
     uint32_t* d_status = (uint32_t*)(d_thr + nq_pad);
@@ -411,9 +416,9 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     uint2* d_lists = nullptr;
     uint32_t* d_counts = nullptr;
     if (mfma) {
-        VROD_TRY(idx->lists.ensure((size_t)nq_pad * cap * 8 + (size_t)nq_pad * 4));
-        d_lists = idx->lists.as<uint2>();
-        d_counts = (uint32_t*)((char*)idx->lists.p + (size_t)nq_pad * cap * 8);
+        VROD_TRY(P.lists.ensure((size_t)nq_pad * cap * 8 + (size_t)nq_pad * 4));
+        d_lists = P.lists.as<uint2>();
+        d_counts = (uint32_t*)((char*)P.lists.p + (size_t)nq_pad * cap * 8);
     }
     const uint32_t worst_bits = idx->metric == VROD_METRIC_COSINE ? 0xFF800000u : 0x7F800000u;  // -inf / +inf
     QueryInit qi{};
@@ -422,31 +427,31 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     qi.thr = mfma ? d_thr : nullptr;
     qi.thr_live_bits = worst_bits;
     qi.thr_pad_bits = worst_bits ^ 0x80000000u;
-    qi.zero_words = &idx->flags[1];   // max |q|^2 bits, max err bits
+    qi.zero_words = &P.flags[1];   // max |q|^2 bits, max err bits
     qi.n_zero_words = 2;
     // pacing counters: 8 regions of 192 words behind the scalars, one per scan launch of this search
     constexpr uint32_t kPaceRegions = 8, kPaceWords = 192;
-    uint32_t* pace_base = idx->flags + 64;
+    uint32_t* pace_base = P.flags + 64;
     qi.zero_words2 = mfma ? pace_base : nullptr;
     qi.n_zero_words2 = kPaceRegions * kPaceWords;
     const size_t hist_words = 8 * 4096 + 8;   // stream path: [8][<=4096] bin counters + 8 key counters
     if (path == VROD_PATH_STREAM) {
-        VROD_TRY(idx->hist.ensure(hist_words * 4));
-        qi.zero_words2 = idx->hist.as<uint32_t>();   // first pass of 8 queries: cleared by the prep launch
+        VROD_TRY(P.hist.ensure(hist_words * 4));
+        qi.zero_words2 = P.hist.as<uint32_t>();   // first pass of 8 queries: cleared by the prep launch
         qi.n_zero_words2 = (uint32_t)hist_words;
     }
     uint32_t pace_launch = 0;
     launch_prep_queries(d_queries_raw, nq, nq_pad, idx->dim, idx->ld, idx->metric, idx->dtype, P.q_f32.as<float>(),
-                        q_lp, d_qn2, &idx->flags[0], &idx->flags[1], qi, s);
+                        q_lp, d_qn2, &P.flags[0], &P.flags[1], qi, s);
     HIP_TRY(hipGetLastError());
 
     const float u = 5.9604645e-8f;  // 2^-24
     int eps_mode = 0;
     float eps_c = 0.f;
 
-    VROD_TRY(idx->cand_rows.ensure((size_t)nq * kp * 4));
-    VROD_TRY(idx->cand_fast.ensure((size_t)nq * kp * 4));
-    VROD_TRY(idx->cand_canon.ensure((size_t)nq * kp * 4));
+    VROD_TRY(P.cand_rows.ensure((size_t)nq * kp * 4));
+    VROD_TRY(P.cand_fast.ensure((size_t)nq * kp * 4));
+    VROD_TRY(P.cand_canon.ensure((size_t)nq * kp * 4));
 
     const double row_bytes_alg = (double)idx->ld * idx->esize;
 
@@ -455,10 +460,10 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         if (idx->metric == VROD_METRIC_COSINE) { eps_mode = 0; eps_c = 4.f * idx->dim * u; }
         else { eps_mode = 1; eps_c = 4.f * (idx->dim + 2) * u; }
         const uint64_t score_ld = round_up(N, 64);
-        VROD_TRY(idx->scores.ensure((size_t)8 * score_ld * 4));
+        VROD_TRY(P.scores.ensure((size_t)8 * score_ld * 4));
         // radix select, pass 1 fused into the scan (histogram buffer prepared above)
-        VROD_TRY(idx->keys_a.ensure((size_t)8 * kSelectChunk * 8));
-        uint32_t* d_hist = idx->hist.as<uint32_t>();
+        VROD_TRY(P.keys_a.ensure((size_t)8 * kSelectChunk * 8));
+        uint32_t* d_hist = P.hist.as<uint32_t>();
         uint32_t* d_cnt = d_hist + 8 * 4096;
         for (uint32_t q0 = 0; q0 < nq; q0 += 8) {
             const int nqc = (int)std::min<uint32_t>(8, nq - q0);
@@ -468,16 +473,16 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
             size_t a, b;
             tm.arm(a, b);
             launch_scan_stream(idx->corpus, idx->dtype, idx->metric, idx->ld, N,
-                               P.q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, idx->scores.as<float>(), score_ld,
+                               P.q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, P.scores.as<float>(), score_ld,
                                d_hist, kp, s);
             P.scan_pairs.push_back({a, b});
             st.scan_launches++;
             st.scan_bytes += (double)N * row_bytes_alg;
             st.scan_flops += 2.0 * nqc * (double)N * idx->dim;
-            launch_hist_compact(idx->scores.as<float>(), score_ld, N, nqc, idx->metric, d_hist, stream_hist_bits(nqp), kp,
-                                idx->keys_a.as<uint64_t>(), kSelectChunk, d_cnt, d_status + q0, s);
-            launch_keys_to_candidates(idx->keys_a.as<uint64_t>(), kSelectChunk, kSelectChunk, nqc, idx->metric, kp,
-                                      idx->cand_rows.as<uint32_t>() + (size_t)q0 * kp, idx->cand_fast.as<float>() + (size_t)q0 * kp,
+            launch_hist_compact(P.scores.as<float>(), score_ld, N, nqc, idx->metric, d_hist, stream_hist_bits(nqp), kp,
+                                P.keys_a.as<uint64_t>(), kSelectChunk, d_cnt, d_status + q0, s);
+            launch_keys_to_candidates(P.keys_a.as<uint64_t>(), kSelectChunk, kSelectChunk, nqc, idx->metric, kp,
+                                      P.cand_rows.as<uint32_t>() + (size_t)q0 * kp, P.cand_fast.as<float>() + (size_t)q0 * kp,
                                       d_T + q0, d_cnt, s);
         }
         HIP_TRY(hipGetLastError());
@@ -487,6 +492,12 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         // (4) keep the best k' of every list.
         if (idx->metric == VROD_METRIC_COSINE) { eps_mode = 0; eps_c = 4.f * idx->dim * u; }
         else { eps_mode = 2; eps_c = 4.f * (idx->dim + 4) * u; }
+        // the MFMA scans own the whole chip: start them only when the other slot's search is
+        // through (its tail then overlaps this search's head: query synthesis / preparation)
+        {
+            Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
+            if (O.done) HIP_TRY(hipStreamWaitEvent(s, O.done, 0));
+        }
         const void* qmat = idx->dtype == VROD_DTYPE_BF16 ? q_lp : P.q_f32.p;
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
@@ -497,9 +508,9 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
             const StagePlan sp = plan_stages(N, kp, cap, std::max<uint32_t>(1, (uint32_t)idx->num_cus / nqb) * kRowTile);
             bounds = sp.bounds;
             const uint32_t dense_ld = (uint32_t)round_up(sp.S, kRowTile);
-            VROD_TRY(idx->scores.ensure((size_t)nq_pad * dense_ld * 4));
+            VROD_TRY(P.scores.ensure((size_t)nq_pad * dense_ld * 4));
             MfmaScanArgs d = a;
-            d.row_begin = 0; d.row_end = sp.S; d.dense_out = idx->scores.as<float>(); d.dense_ld = dense_ld;
+            d.row_begin = 0; d.row_end = sp.S; d.dense_out = P.scores.as<float>(); d.dense_ld = dense_ld;
             d.pace = pace_base; d.pace_is_zero = true; ++pace_launch;
             size_t e0, e1;
             tm.arm(e0, e1);
@@ -508,7 +519,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
             st.scan_launches++;
             st.scan_bytes += (double)dense_ld * row_bytes_alg;
             st.scan_flops += 2.0 * nq * (double)sp.S * idx->dim;
-            launch_sample_select(idx->scores.as<float>(), dense_ld, sp.S, (int)nq, idx->metric, sp.j, d_thr, s);
+            launch_sample_select(P.scores.as<float>(), dense_ld, sp.S, (int)nq, idx->metric, sp.j, d_thr, s);
         }
         uint64_t lo = 0;
         for (size_t li = 0; li < bounds.size(); ++li) {
@@ -530,7 +541,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
             }
             const bool last = li + 1 == bounds.size();
             launch_list_compact(d_lists, d_counts, cap, (int)nq, idx->metric, kp, d_thr, d_status,
-                                last ? idx->cand_rows.as<uint32_t>() : nullptr, last ? idx->cand_fast.as<float>() : nullptr,
+                                last ? P.cand_rows.as<uint32_t>() : nullptr, last ? P.cand_fast.as<float>() : nullptr,
                                 last ? d_T : nullptr, s);
         }
         HIP_TRY(hipGetLastError());
@@ -541,12 +552,12 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     if (path != VROD_PATH_EXACT) {
         // -------- canonical re-score + final ordering + certificate
         launch_rescore_candidates(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.q_f32.as<float>(), (int)nq,
-                                  idx->cand_rows.as<uint32_t>(), kp, idx->cand_canon.as<float>(), s);
-        launch_final_topk(idx->cand_rows.as<uint32_t>(), idx->cand_fast.as<float>(), idx->cand_canon.as<float>(), d_T, (int)nq, kp, k,
-                          idx->metric, idx->id_offset, eps_mode, eps_c, &idx->flags[1], idx->max_xn2_bits, d_out_ids, d_out_scores,
-                          d_status, (float*)&idx->flags[2], s);
+                                  P.cand_rows.as<uint32_t>(), kp, P.cand_canon.as<float>(), s);
+        launch_final_topk(P.cand_rows.as<uint32_t>(), P.cand_fast.as<float>(), P.cand_canon.as<float>(), d_T, (int)nq, kp, k,
+                          idx->metric, idx->id_offset, eps_mode, eps_c, &P.flags[1], idx->max_xn2_bits, d_out_ids, d_out_scores,
+                          d_status, (float*)&P.flags[2], s);
     }
-    launch_gather_readback(d_status, nq, idx->flags, idx->max_xn2_bits, d_readback, s);
+    launch_gather_readback(d_status, nq, P.flags, idx->max_xn2_bits, d_readback, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(P.h_readback, d_readback, ((size_t)nq + 4) * 4, hipMemcpyDeviceToHost, s));
     P.t1 = tm.mark();
@@ -558,7 +569,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
 // queries whose certificate failed (enqueued behind whatever the stream holds by now).
 static int search_complete(vrod_index* idx, Pending& P) {
     vrod_search_stats& st = P.st;
-    hipStream_t s = idx->stream;
+    hipStream_t s = P.stream;
     Timer tm(idx, P);
     const uint32_t nq = P.nq, k = P.k;
     const uint64_t N = P.N;
@@ -593,12 +604,12 @@ static int search_complete(vrod_index* idx, Pending& P) {
         if (!hstatus[qi]) continue;
         st.fallback_queries++;
         const uint64_t score_ld = round_up(N, 64);
-        VROD_TRY(idx->scores.ensure((size_t)score_ld * 4));
+        VROD_TRY(P.scores.ensure((size_t)score_ld * 4));
         launch_rescore_all(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.q_f32.as<float>() + (size_t)qi * idx->ld, N,
-                           idx->scores.as<float>(), s);
+                           P.scores.as<float>(), s);
         const uint32_t kx = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(k, N), kSelectChunk / 2);
         const uint64_t* keys; uint64_t kld, kn;
-        VROD_TRY(select_chain(idx, idx->scores.as<float>(), score_ld, N, 1, kx, &keys, &kld, &kn));
+        VROD_TRY(select_chain(idx, P, P.scores.as<float>(), score_ld, N, 1, kx, &keys, &kld, &kn));
         launch_keys_to_output(keys, kn, idx->metric, k, idx->id_offset, P.out_ids + (size_t)qi * k, P.out_scores + (size_t)qi * k, s);
         HIP_TRY(hipGetLastError());
     }
@@ -622,9 +633,9 @@ static int search_begin(vrod_index* idx, const float* d_queries_raw, uint32_t nq
     int rc = search_enqueue(idx, P, d_queries_raw, nq, k, d_out_ids, d_out_scores);
     if (rc != VROD_OK) {
         // a half-enqueued search: drain the stream, consume the bad-value flag, leave the slot free
-        (void)hipStreamSynchronize(idx->stream);
-        (void)hipMemsetAsync(&idx->flags[0], 0, 4, idx->stream);
-        (void)hipStreamSynchronize(idx->stream);
+        (void)hipStreamSynchronize(P.stream);
+        (void)hipMemsetAsync(&P.flags[0], 0, 4, P.stream);
+        (void)hipStreamSynchronize(P.stream);
         return rc;
     }
     P.active = true;
@@ -639,6 +650,9 @@ static int search_end(vrod_index* idx) {
     P.active = false;
     return search_complete(idx, P);
 }
+
+// the slot (stream, raw-query buffer) the next search_begin will use
+static Pending& next_slot(vrod_index* idx) { return idx->slot[idx->n_begun & 1]; }
 
 static int run_search(vrod_index* idx, const float* d_queries_raw, uint32_t nq, uint32_t k,
                       uint64_t* d_out_ids, float* d_out_scores) {
@@ -656,7 +670,7 @@ static int require_idle(const vrod_index* idx, const char* what) {
 static int order_after_caller(vrod_index* idx, void* stream) {
     if (!idx->caller_ev) HIP_TRY(hipEventCreateWithFlags(&idx->caller_ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(idx->caller_ev, (hipStream_t)stream));
-    HIP_TRY(hipStreamWaitEvent(idx->stream, idx->caller_ev, 0));
+    HIP_TRY(hipStreamWaitEvent(next_slot(idx).stream, idx->caller_ev, 0));
     return VROD_OK;
 }
 
@@ -731,7 +745,7 @@ static int composite_search(vrod_index* idx, const float* queries, bool from_hos
         vrod_index* sh = idx->shards[g];
         if ((rc = set_device(sh)) != VROD_OK || (rc = idx->sh_q[g].ensure(qbytes)) != VROD_OK ||
             (rc = idx->sh_ids[g].ensure(nk * 8)) != VROD_OK || (rc = idx->sh_scores[g].ensure(nk * 4)) != VROD_OK) break;
-        if (hipMemcpyAsync(idx->sh_q[g].p, queries, qbytes, from_host ? hipMemcpyHostToDevice : hipMemcpyDefault, sh->stream) != hipSuccess) {
+        if (hipMemcpyAsync(idx->sh_q[g].p, queries, qbytes, from_host ? hipMemcpyHostToDevice : hipMemcpyDefault, next_slot(sh).stream) != hipSuccess) {
             rc = fail(VROD_ERR_HIP, "query upload to device %d failed", sh->device);
             break;
         }
@@ -837,6 +851,12 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
         if (hipMalloc((void**)&idx->flags, 8192) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
         if (hipMemset(idx->flags, 0, 8192) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
         idx->max_xn2_bits = idx->flags + 8;
+        for (Pending& P : idx->slot) {
+            if (hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipStreamCreate failed"); break; }
+            if (hipMalloc((void**)&P.flags, 8192) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
+            if (hipMemset(P.flags, 0, 8192) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
+            if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipEventCreate failed"); break; }
+        }
     } while (0);
     if (rc != VROD_OK) { vrod_index_destroy(idx); return rc; }
     *out = idx;
@@ -851,18 +871,21 @@ int vrod_index_destroy(vrod_index* idx) {
             if (g < idx->sh_q.size()) { idx->sh_q[g].release(); idx->sh_ids[g].release(); idx->sh_scores[g].release(); }
         }
         (void)hipSetDevice(idx->device);
-        idx->gather.release(); idx->out_ids.release(); idx->out_scores.release(); idx->q_raw.release();
+        idx->gather.release(); idx->out_ids.release(); idx->out_scores.release(); idx->raw_stage.release();
         for (vrod_index* sh : idx->shards) vrod_index_destroy(sh);
         delete idx;
         return VROD_OK;
     }
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    for (DevBuf* b : {&idx->raw_stage, &idx->nrm_ws, &idx->q_raw, &idx->q_lp, &idx->scores, &idx->keys_a,
-                      &idx->keys_b, &idx->lists, &idx->small, &idx->hist, &idx->cand_rows, &idx->cand_fast, &idx->cand_canon,
-                      &idx->out_ids, &idx->out_scores})
-        b->release();
+    for (Pending& P : idx->slot)
+        if (P.stream) (void)hipStreamSynchronize(P.stream);
+    for (DevBuf* b : {&idx->raw_stage, &idx->nrm_ws, &idx->out_ids, &idx->out_scores}) b->release();
     for (Pending& P : idx->slot) {
+        for (DevBuf* b : {&P.q_raw, &P.q_lp, &P.scores, &P.keys_a, &P.keys_b, &P.lists, &P.small, &P.hist, &P.cand_rows, &P.cand_fast, &P.cand_canon})
+            b->release();
+        if (P.flags) (void)hipFree(P.flags);
+        if (P.stream) (void)hipStreamDestroy(P.stream);
         P.q_f32.release();
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
         if (P.done) (void)hipEventDestroy(P.done);
@@ -969,9 +992,10 @@ int vrod_search_begin_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t 
     VROD_TRY(order_after_caller(idx, stream));
     // the raw queries are consumed by the prepare launch of this same search: one shared buffer,
     // stream-ordered (a regrowth frees it through hipFree, which waits for the device)
-    VROD_TRY(idx->q_raw.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
-    launch_synth_rows(seed, first_row, nq, idx->dim, idx->q_raw.as<float>(), idx->stream);
-    return search_begin(idx, idx->q_raw.as<float>(), nq, k, d_out_ids, d_out_scores);
+    Pending& P = next_slot(idx);
+    VROD_TRY(P.q_raw.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
+    launch_synth_rows(seed, first_row, nq, idx->dim, P.q_raw.as<float>(), P.stream);
+    return search_begin(idx, P.q_raw.as<float>(), nq, k, d_out_ids, d_out_scores);
 }
 
 int vrod_search_end(vrod_index* idx) {
@@ -994,17 +1018,18 @@ int vrod_search_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t first_
         vrod_index* s0 = idx->shards[0];
         VROD_TRY(set_device(s0));
         if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        VROD_TRY(idx->q_raw.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
-        launch_synth_rows(seed, first_row, nq, idx->dim, idx->q_raw.as<float>(), s0->stream);
+        VROD_TRY(idx->raw_stage.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
+        launch_synth_rows(seed, first_row, nq, idx->dim, idx->raw_stage.as<float>(), s0->stream);
         HIP_TRY(hipStreamSynchronize(s0->stream));
-        return composite_search(idx, idx->q_raw.as<float>(), false, nq, k, d_out_ids, d_out_scores);
+        return composite_search(idx, idx->raw_stage.as<float>(), false, nq, k, d_out_ids, d_out_scores);
     }
     VROD_TRY(require_idle(idx, "vrod_search_synthetic_device"));
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));
-    VROD_TRY(idx->q_raw.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
-    launch_synth_rows(seed, first_row, nq, idx->dim, idx->q_raw.as<float>(), idx->stream);
-    return run_search(idx, idx->q_raw.as<float>(), nq, k, d_out_ids, d_out_scores);
+    Pending& P = next_slot(idx);
+    VROD_TRY(P.q_raw.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
+    launch_synth_rows(seed, first_row, nq, idx->dim, P.q_raw.as<float>(), P.stream);
+    return run_search(idx, P.q_raw.as<float>(), nq, k, d_out_ids, d_out_scores);
 }
 
 int vrod_search(vrod_index* idx, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_ids,
@@ -1014,11 +1039,12 @@ int vrod_search(vrod_index* idx, const float* queries, uint32_t nq, uint32_t k, 
     if (idx->composite()) return composite_search(idx, queries, true, nq, k, out_ids, out_scores);
     VROD_TRY(require_idle(idx, "vrod_search"));
     VROD_TRY(set_device(idx));
-    VROD_TRY(idx->q_raw.ensure((size_t)nq * idx->dim * 4));
+    Pending& P = next_slot(idx);
+    VROD_TRY(P.q_raw.ensure((size_t)nq * idx->dim * 4));
     VROD_TRY(idx->out_ids.ensure((size_t)nq * k * 8));
     VROD_TRY(idx->out_scores.ensure((size_t)nq * k * 4));
-    HIP_TRY(hipMemcpyAsync(idx->q_raw.p, queries, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, idx->stream));
-    VROD_TRY(run_search(idx, idx->q_raw.as<float>(), nq, k, idx->out_ids.as<uint64_t>(), idx->out_scores.as<float>()));
+    HIP_TRY(hipMemcpyAsync(P.q_raw.p, queries, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, P.stream));
+    VROD_TRY(run_search(idx, P.q_raw.as<float>(), nq, k, idx->out_ids.as<uint64_t>(), idx->out_scores.as<float>()));
     HIP_TRY(hipMemcpyAsync(out_ids, idx->out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipMemcpyAsync(out_scores, idx->out_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipStreamSynchronize(idx->stream));
