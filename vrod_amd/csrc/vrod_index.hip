@@ -105,6 +105,7 @@ struct Pending {
     uint32_t* h_readback = nullptr;   // pinned host block: status[nq] + 4 scalars, one D2H per search
     size_t h_readback_words = 0;
     hipEvent_t done = nullptr;     // recorded behind the D2H
+    hipEvent_t scans_done = nullptr;   // MFMA path: recorded behind the last scan launch
     std::vector<hipEvent_t> ev;    // profiling events
     size_t ev_used = 0, t0 = 0, t1 = 0;
     std::vector<std::pair<size_t, size_t>> scan_pairs;
@@ -492,12 +493,12 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         // (4) keep the best k' of every list.
         if (idx->metric == VROD_METRIC_COSINE) { eps_mode = 0; eps_c = 4.f * idx->dim * u; }
         else { eps_mode = 2; eps_c = 4.f * (idx->dim + 4) * u; }
-        // the MFMA scans own the whole chip: start them only when the other slot's search is
-        // through (its tail then overlaps this search's head: query synthesis / preparation)
-        {
-            Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
-            if (O.done) HIP_TRY(hipStreamWaitEvent(s, O.done, 0));
-        }
+        // The MFMA scans own the whole chip.  The dense sample pass starts when the other slot's
+        // last scan is through, the first filtered stage when that whole search is: the other
+        // search's tail (compaction, re-score, certificate, read-back) then runs beside this
+        // one's head (query preparation, sample selection) and is never held up by a long stage.
+        Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
+        HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
         const void* qmat = idx->dtype == VROD_DTYPE_BF16 ? q_lp : P.q_f32.p;
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
@@ -521,6 +522,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
             st.scan_flops += 2.0 * nq * (double)sp.S * idx->dim;
             launch_sample_select(P.scores.as<float>(), dense_ld, sp.S, (int)nq, idx->metric, sp.j, d_thr, s);
         }
+        HIP_TRY(hipStreamWaitEvent(s, O.done, 0));
         uint64_t lo = 0;
         for (size_t li = 0; li < bounds.size(); ++li) {
             while (lo < bounds[li]) {
@@ -540,6 +542,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
                 lo = end;
             }
             const bool last = li + 1 == bounds.size();
+            if (last) HIP_TRY(hipEventRecord(P.scans_done, s));
             launch_list_compact(d_lists, d_counts, cap, (int)nq, idx->metric, kp, d_thr, d_status,
                                 last ? P.cand_rows.as<uint32_t>() : nullptr, last ? P.cand_fast.as<float>() : nullptr,
                                 last ? d_T : nullptr, s);
@@ -855,7 +858,8 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
             if (hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipStreamCreate failed"); break; }
             if (hipMalloc((void**)&P.flags, 8192) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
             if (hipMemset(P.flags, 0, 8192) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
-            if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipEventCreate failed"); break; }
+            if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&P.scans_done, hipEventDisableTiming) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipEventCreate failed"); break; }
         }
     } while (0);
     if (rc != VROD_OK) { vrod_index_destroy(idx); return rc; }
@@ -889,6 +893,7 @@ int vrod_index_destroy(vrod_index* idx) {
         P.q_f32.release();
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
         if (P.done) (void)hipEventDestroy(P.done);
+        if (P.scans_done) (void)hipEventDestroy(P.scans_done);
         if (P.h_readback) (void)hipHostFree(P.h_readback);
     }
     if (idx->caller_ev) (void)hipEventDestroy(idx->caller_ev);
