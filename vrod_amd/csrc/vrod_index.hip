@@ -105,7 +105,7 @@ struct Pending {
     uint32_t* h_readback = nullptr;   // pinned host block: status[nq] + 4 scalars, one D2H per search
     size_t h_readback_words = 0;
     hipEvent_t done = nullptr;     // recorded behind the D2H
-    hipEvent_t scans_done = nullptr;   // MFMA path: recorded behind the last scan launch
+    hipEvent_t scans_done = nullptr;   // recorded behind the last scan launch
     std::vector<hipEvent_t> ev;    // profiling events
     size_t ev_used = 0, t0 = 0, t1 = 0;
     std::vector<std::pair<size_t, size_t>> scan_pairs;
@@ -466,6 +466,12 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         VROD_TRY(P.keys_a.ensure((size_t)8 * kSelectChunk * 8));
         uint32_t* d_hist = P.hist.as<uint32_t>();
         uint32_t* d_cnt = d_hist + 8 * 4096;
+        // one HBM-bound scan at a time (two would only share the bandwidth and stretch each
+        // other); everything behind the scan overlaps the other slot's scan
+        {
+            Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
+            HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
+        }
         for (uint32_t q0 = 0; q0 < nq; q0 += 8) {
             const int nqc = (int)std::min<uint32_t>(8, nq - q0);
             int nqp = 1;
@@ -477,6 +483,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
                                P.q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, P.scores.as<float>(), score_ld,
                                d_hist, kp, s);
             P.scan_pairs.push_back({a, b});
+            if (q0 + 8 >= nq) HIP_TRY(hipEventRecord(P.scans_done, s));
             st.scan_launches++;
             st.scan_bytes += (double)N * row_bytes_alg;
             st.scan_flops += 2.0 * nqc * (double)N * idx->dim;
