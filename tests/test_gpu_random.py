@@ -11,9 +11,11 @@ ME = {"cosine": 0, "l2": 1}
 
 
 def _cases():
-    rng = np.random.default_rng(20261004)
+    # VROD_RANDOM_SEED / VROD_RANDOM_CASES: one-off larger sweeps (the defaults are the committed suite)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("VROD_RANDOM_SEED", "20261004")))
     out = []
-    for i in range(36):
+    for i in range(int(os.environ.get("VROD_RANDOM_CASES", "36"))):
         n = int(rng.choice([1, 2, 63, 257, 1000, 4097, 9000, 20011, 70001]))
         dim = int(rng.choice([1, 3, 31, 32, 33, 64, 100, 129, 257, 384]))
         nq = int(rng.choice([1, 2, 7, 8, 9, 17, 255, 256, 257]))
