@@ -84,8 +84,7 @@ static inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m
 // for that copy, read the certificate's verdicts, run the exact path for the rare failures).  Two
 // slots let the caller enqueue search s+1 before it completes search s, so the device never waits
 // for the host between batches and the caller's exchange of batch s (all-gather + merge on its own
-// stream) overlaps the scan of batch s+1.  Everything a completion may still need after the next
-// search has been enqueued lives in the slot; the other workspaces are shared and stream-ordered.
+// stream) overlaps the scan of batch s+1.
 struct Pending {
     bool active = false;
     bool trivial = false;          // nq == 0 or empty corpus: the outputs are already final
