@@ -84,7 +84,9 @@ struct MfmaKernelArgs {
     uint2* lists;
     uint32_t* counts;
     uint32_t cap;
-    uint32_t ld_bytes;      // bytes per row (multiple of 128)
+    uint32_t ld_bytes;      // bytes per row (multiple of 128); in the 4-wave kernel: per QUERY row = the K extent
+    uint32_t lda_bytes;     // 4-wave kernel: bytes per CORPUS row, and after how many K-tiles a corpus row is
+    uint32_t a_wrap;        // walked again from its start (split-bf16 pass over fp32 rows: [hi|lo] x [hi|hi|lo])
     uint32_t nqb;           // query blocks of 256
     uint32_t tile_first;    // first 256-row tile of the launch
     uint32_t ntiles;        // tiles in the launch
@@ -817,7 +819,9 @@ __device__ __forceinline__ void w4_dense_store_tile(const MfmaKernelArgs& a, con
     });
 }
 
-template <int METRIC, bool DENSE>
+// SPLIT: the corpus row stride differs from the K extent and a corpus row is walked more than once per
+// tile (bf16 split pass over fp32 rows); a template parameter so that the plain form carries no extra state.
+template <int METRIC, bool DENSE, bool SPLIT>
 __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // makes the kernel descriptor allocate a[0:255]
@@ -840,12 +844,14 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
     const uint32_t KT = a.ld_bytes >> 7;
     const uint32_t rel_base = a.tile_first * kBM;
     const uint32_t st_row = lane >> 3;
-    const uint32_t st_lane_off = st_row * a.ld_bytes + (((lane & 7) ^ st_row) << 4);
+    const uint32_t lda_bytes = SPLIT ? a.lda_bytes : a.ld_bytes;
+    const uint32_t st_lane_off_a = st_row * lda_bytes + (((lane & 7) ^ st_row) << 4);
+    const uint32_t st_lane_off_b = st_row * a.ld_bytes + (((lane & 7) ^ st_row) << 4);
     const uint32_t fr = lane & 15, fg = lane >> 4, r7 = fr & 7;
     const uint32_t a_frag0 = ((wr * 16 + (fr >> 3)) << 10) + (r7 << 7);
     const uint32_t b_frag0 = 32768u + ((wc * 16 + (fr >> 3)) << 10) + (r7 << 7);
     const uint32_t c_off0 = ((0 * 4 + fg) ^ r7) << 4, c_off1 = ((1 * 4 + fg) ^ r7) << 4;
-    const uint64_t piece_stride = 8ull * a.ld_bytes;
+    const uint32_t piece_stride_a = 8u * lda_bytes, piece_stride_b = 8u * a.ld_bytes;   // 8 rows; 31 pieces fit 32 bits
     const uint32_t total_it = (t1 - t0) * KT;
 
     // ONE query block per work-group: a loop over query blocks here would re-enter the prologue with the
@@ -860,38 +866,48 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         qn2_l[tid] = METRIC == M_L2 ? a.qnorm2[qb * kBN + tid] : 0.0f;
         // (published by the prologue's __syncthreads)
         // per-lane source pointers of the K-tile being staged (two K-tiles ahead of the MFMAs)
-        const char* ua_src = a.corpus + st_lane_off + (uint64_t)t0 * kBM * a.ld_bytes;
-        const char* ub_src = a.queries + st_lane_off + (uint64_t)qb * kBN * a.ld_bytes;
-        uint32_t st_kt = 0, st_tile = t0;
+        const char* ua_src = a.corpus + st_lane_off_a + (uint64_t)t0 * kBM * lda_bytes;
+        const char* ub_src = a.queries + st_lane_off_b + (uint64_t)qb * kBN * a.ld_bytes;
+        uint32_t st_kt = 0, st_tile = t0, a_kt = 0;   // a_kt: K-tile of the corpus row ua_src points at
         // unit A_mh / B_nh = the 16 pieces (8 rows x 128 B each) of rows [h*64, h*64+64) of both
         // 128-row halves; this wave moves 4 of them: idx = wave*4 + i -> piece (idx>>3)*16 + (idx&7) + h*8
-        auto stage_unit = [&](uint32_t buf, bool is_b, int h, int i) {
+        auto stage_a = [&](uint32_t buf, int h, int i) {
             const uint32_t idx = wave * 4 + i;
             const uint32_t p = (idx >> 3) * 16 + (idx & 7) + h * 8;
-            char* l = lds + (buf & 1) * kStageBytes + (is_b ? 32768 : 0) + p * 1024;
-            VROD_GLDS16((is_b ? ub_src : ua_src) + (uint64_t)p * piece_stride, l);
+            VROD_GLDS16(ua_src + p * piece_stride_a, lds + (buf & 1) * kStageBytes + p * 1024);
+        };
+        auto stage_b = [&](uint32_t buf, int h, int i) {
+            const uint32_t idx = wave * 4 + i;
+            const uint32_t p = (idx >> 3) * 16 + (idx & 7) + h * 8;
+            VROD_GLDS16(ub_src + p * piece_stride_b, lds + (buf & 1) * kStageBytes + 32768 + p * 1024);
         };
         // next K-tile of the strip (clamped at its end: the last K-tile is re-staged, never read)
         auto stage_advance = [&]() {
-            if (st_kt + 1 < KT) { ++st_kt; ua_src += 128; ub_src += 128; }
-            else if (st_tile + 1 < t1) {
-                st_kt = 0; ++st_tile;
-                ua_src += (uint64_t)kBM * a.ld_bytes - (uint64_t)(KT - 1) * 128;
-                ub_src -= (uint64_t)(KT - 1) * 128;
-            }
+            // one update site per pointer (uniform deltas picked by selects): written as branches
+            // with in-place updates, hipcc moves the two pointers into a scratch array
+            const bool in_tile = st_kt + 1 < KT;
+            const bool next_tile = !in_tile && st_tile + 1 < t1;
+            const bool wrap = SPLIT && a_kt + 1 == a.a_wrap;
+            const int64_t da_in = wrap ? -(int64_t)(a.a_wrap - 1) * 128 : 128;
+            const int64_t a_back = SPLIT ? (int64_t)a_kt * 128 : (int64_t)(KT - 1) * 128;
+            const int64_t da = in_tile ? da_in : next_tile ? (int64_t)kBM * lda_bytes - a_back : 0;
+            const int64_t db = in_tile ? 128 : next_tile ? -(int64_t)(KT - 1) * 128 : 0;
+            if constexpr (SPLIT) a_kt = in_tile ? (wrap ? 0u : a_kt + 1) : next_tile ? 0u : a_kt;
+            st_kt = in_tile ? st_kt + 1 : next_tile ? 0u : st_kt;
+            st_tile += next_tile ? 1u : 0u;
+            ua_src += da;
+            ub_src += db;
         };
 
         // ---- prologue: K-tiles 0 and 1 whole, landed; fragments A0, B0 of K-tile 0
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int b = 0; b < 2; ++b) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) stage_unit(0, u == 1 || u == 2, u >> 1, i);
-        stage_advance();
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) stage_unit(1, u == 1 || u == 2, u >> 1, i);
-        stage_advance();
+                for (int i = 0; i < 4; ++i) { stage_a(b, h, i); stage_b(b, h, i); }
+            stage_advance();
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
@@ -909,10 +925,10 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
     w4_mfma_group<MH, NH, ZERO, 7>(FA, FB);
 #define W4_PHASE(FA, FB, MH, NH, LD, DM)                                                           \
     if (first) { W4_PHASE_S(FA, FB, MH, NH, true, LD, DM) } else { W4_PHASE_S(FA, FB, MH, NH, false, LD, DM) }
-#define W4_DMU0(j) stage_unit(it & 1, false, 0, j);
-#define W4_DMU1(j) stage_unit(it & 1, true, 0, j);
-#define W4_DMU2(j) stage_unit(it & 1, true, 1, j);
-#define W4_DMU3(j) stage_unit(it & 1, false, 1, j);
+#define W4_DMU0(j) stage_a(it & 1, 0, j);
+#define W4_DMU1(j) stage_b(it & 1, 0, j);
+#define W4_DMU2(j) stage_b(it & 1, 1, j);
+#define W4_DMU3(j) stage_a(it & 1, 1, j);
 #define W4_VMWAIT "s_waitcnt vmcnt(16) lgkmcnt(0)"
 #define W4_ITER(BX, BY, LDQ0, LDQ3)                                                                \
     {                                                                                              \
@@ -1017,6 +1033,8 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     a.counts = h.counts;
     a.cap = h.cap;
     a.ld_bytes = h.ld * (dtype == DT_BF16 ? 2u : 4u);
+    a.lda_bytes = h.lda_bytes ? h.lda_bytes : a.ld_bytes;
+    a.a_wrap = h.a_wrap ? h.a_wrap : (a.ld_bytes >> 7);
     a.nqb = h.nq_pad / kBN;
     a.tile_first = h.row_begin / kBM;
     a.ntiles = (h.row_end + kBM - 1) / kBM - a.tile_first;
@@ -1048,18 +1066,20 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     static const int gp = [] { const char* e = getenv("VROD_MFMA_GP"); return e ? atoi(e) : 0; }();
     static const bool w4 = [] { const char* e = getenv("VROD_MFMA_W4"); return !e || e[0] != '0'; }();
     static const int pace_kt = [] { const char* e = getenv("VROD_MFMA_PACE_KT"); return e ? atoi(e) : 192; }();
-#define VROD_MFMA_W4K(MM, DN)                                                                               \
+#define VROD_MFMA_W4K_(MM, DN, SP)                                                                          \
     do {                                                                                                    \
         static bool attr_set = false;                                                                       \
         if (!attr_set) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)scan_mfma_w4_kernel<MM, DN>,                             \
+            (void)hipFuncSetAttribute((const void*)scan_mfma_w4_kernel<MM, DN, SP>,                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotalW4);             \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        hipExtLaunchKernelGGL((scan_mfma_w4_kernel<MM, DN>), dim3(grid), dim3(256), kLdsTotalW4, s,            \
+        hipExtLaunchKernelGGL((scan_mfma_w4_kernel<MM, DN, SP>), dim3(grid), dim3(256), kLdsTotalW4, s,        \
                               first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr, 0, a);        \
     } while (0)
-    if (dtype == DT_BF16 && w4 && !simple) {
+#define VROD_MFMA_W4K(MM, DN) do { if (split) VROD_MFMA_W4K_(MM, DN, true); else VROD_MFMA_W4K_(MM, DN, false); } while (0)
+    const bool split = h.lda_bytes != 0 && (h.lda_bytes != a.ld_bytes || h.a_wrap != (a.ld_bytes >> 7));
+    if (dtype == DT_BF16 && (w4 || split) && !simple) {
         const uint32_t nqb_total = a.nqb;
         for (uint32_t qb_base = 0; qb_base < nqb_total; qb_base += a.slots) {   // one launch unless nq > 256 * slots
             a.qb_base = qb_base;
@@ -1075,6 +1095,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
         return;
     }
 #undef VROD_MFMA_W4K
+#undef VROD_MFMA_W4K_
 #define VROD_MFMA_P(TT, MM, GPV, DN)                                                                            \
     do {                                                                                                    \
         static bool attr_set = false;                                                                       \

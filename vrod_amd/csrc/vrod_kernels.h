@@ -136,7 +136,9 @@ struct MfmaScanArgs {
     uint2* lists;           // [nq_pad][cap] {score bits, row}
     uint32_t* counts;       // [nq_pad]
     uint32_t cap;
-    uint32_t ld;            // elements per row (multiple of 64 bf16 / 32 f32)
+    uint32_t ld;            // elements per row (multiple of 64 bf16 / 32 f32): the K extent, and the query row stride
+    uint32_t lda_bytes;     // 0, or (bf16 4-wave kernel) the corpus row stride in bytes when it differs, with
+    uint32_t a_wrap;        // a_wrap = K-tiles after which a corpus row is walked again from its start
     uint32_t nq_pad;
     uint32_t row_begin;     // appends are limited to rows [row_begin, row_end); the launch
     uint32_t row_end;       // starts at the 256-row tile containing row_begin
