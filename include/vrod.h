@@ -145,7 +145,11 @@ int vrod_merge_topk_packed_device(int device, int metric, const void *d_packed, 
                                   uint32_t nq, uint32_t k, uint64_t *d_out_ids,
                                   float *d_out_scores, void *stream);
 
-/* --- knobs & introspection -------------------------------------------------- */
+/* --- knobs & introspection --------------------------------------------------
+ * Environment, read when a handle is created: VROD_F32_SPLIT=1 -- an F32 handle keeps bf16
+ * [hi | lo] planes of its rows (a second copy of the corpus) and runs batched searches as three
+ * bf16 matrix-core products instead of one fp32 one (2.5x faster at 10M x 1536, batch 256); the
+ * results are the same bits: only the fast pass and the certificate's bound change. */
 int vrod_index_set_path(vrod_index *idx, int path);      /* VROD_PATH_* (default AUTO) */
 int vrod_index_set_profiling(vrod_index *idx, int on);   /* 1: scan_ms (events attached to the scan dispatches), 2: + total_ms (stream markers) */
 int vrod_index_last_stats(const vrod_index *idx, vrod_search_stats *out);

@@ -85,8 +85,8 @@ struct MfmaKernelArgs {
     uint32_t* counts;
     uint32_t cap;
     uint32_t ld_bytes;      // bytes per row (multiple of 128); in the 4-wave kernel: per QUERY row = the K extent
-    uint32_t lda_bytes;     // 4-wave kernel: bytes per CORPUS row, and after how many K-tiles a corpus row is
-    uint32_t a_wrap;        // walked again from its start (split-bf16 pass over fp32 rows: [hi|lo] x [hi|hi|lo])
+    uint32_t lda_bytes;     // 4-wave kernel, SPLIT form: bytes per CORPUS row (the K extent is 3/2 of it: split-bf16
+    uint32_t a_wrap;        // pass over fp32 rows, kernels_prep.hip split_rows_kernel); a_wrap != 0 selects SPLIT
     uint32_t nqb;           // query blocks of 256
     uint32_t tile_first;    // first 256-row tile of the launch
     uint32_t ntiles;        // tiles in the launch
@@ -887,12 +887,14 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
             // with in-place updates, hipcc moves the two pointers into a scratch array
             const bool in_tile = st_kt + 1 < KT;
             const bool next_tile = !in_tile && st_tile + 1 < t1;
-            const bool wrap = SPLIT && a_kt + 1 == a.a_wrap;
-            const int64_t da_in = wrap ? -(int64_t)(a.a_wrap - 1) * 128 : 128;
+            // SPLIT: K-tiles 3j, 3j+1, 3j+2 read corpus K-tile 2j, 2j, 2j+1 ([hi_j | lo_j] interleaved: the
+            // hi plane is staged twice in a row, the second time from L2); a_kt = corpus K-tile
+            const bool hold = SPLIT && (st_kt % 3u) == 0u;
+            const int64_t da_in = hold ? 0 : 128;
             const int64_t a_back = SPLIT ? (int64_t)a_kt * 128 : (int64_t)(KT - 1) * 128;
             const int64_t da = in_tile ? da_in : next_tile ? (int64_t)kBM * lda_bytes - a_back : 0;
             const int64_t db = in_tile ? 128 : next_tile ? -(int64_t)(KT - 1) * 128 : 0;
-            if constexpr (SPLIT) a_kt = in_tile ? (wrap ? 0u : a_kt + 1) : next_tile ? 0u : a_kt;
+            if constexpr (SPLIT) a_kt = in_tile ? (hold ? a_kt : a_kt + 1) : next_tile ? 0u : a_kt;
             st_kt = in_tile ? st_kt + 1 : next_tile ? 0u : st_kt;
             st_tile += next_tile ? 1u : 0u;
             ua_src += da;
@@ -1034,7 +1036,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     a.cap = h.cap;
     a.ld_bytes = h.ld * (dtype == DT_BF16 ? 2u : 4u);
     a.lda_bytes = h.lda_bytes ? h.lda_bytes : a.ld_bytes;
-    a.a_wrap = h.a_wrap ? h.a_wrap : (a.ld_bytes >> 7);
+    a.a_wrap = h.a_wrap;
     a.nqb = h.nq_pad / kBN;
     a.tile_first = h.row_begin / kBM;
     a.ntiles = (h.row_end + kBM - 1) / kBM - a.tile_first;
@@ -1078,7 +1080,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
                               first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr, 0, a);        \
     } while (0)
 #define VROD_MFMA_W4K(MM, DN) do { if (split) VROD_MFMA_W4K_(MM, DN, true); else VROD_MFMA_W4K_(MM, DN, false); } while (0)
-    const bool split = h.lda_bytes != 0 && (h.lda_bytes != a.ld_bytes || h.a_wrap != (a.ld_bytes >> 7));
+    const bool split = h.a_wrap != 0;
     if (dtype == DT_BF16 && (w4 || split) && !simple) {
         const uint32_t nqb_total = a.nqb;
         for (uint32_t qb_base = 0; qb_base < nqb_total; qb_base += a.slots) {   // one launch unless nq > 256 * slots

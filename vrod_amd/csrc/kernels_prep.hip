@@ -228,6 +228,43 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
     if (bad) atomicOr(bad_flag, 1u);
 }
 
+// ------------------------------------------------------------------ bf16 split of fp32 rows
+// x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi) (the subtraction is exact in fp32),
+// |r| <= 2^-16 |x|.  The batched scan of an fp32 corpus can then run on the bf16 matrix cores as
+// q.x ~ hi_q.hi_x + hi_q.lo_x + lo_q.hi_x (16x the fp32 MFMA rate for 3x the products); the
+// certificate's bound covers the representation error (vrod_index.hip).
+// Both layouts are interleaved per K-tile j (64 elements = one 128-B line), so that the scan walks
+// both rows forward and reads the corpus planes from HBM once:
+// MODE 0 (corpus):  out row = [hi_0 | lo_0 | hi_1 | lo_1 | ...]            (2*ldp elements)
+// MODE 1 (queries): out row = [hi_0 | lo_0 | hi_0 | hi_1 | lo_1 | hi_1 ...] (3*ldp elements)
+// and K-tile 3j, 3j+1, 3j+2 of the product pairs corpus (hi_j, hi_j, lo_j) with queries (hi_j, lo_j, hi_j).
+template <int MODE>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, uint64_t n, uint32_t ld,
+                                                         uint32_t ldp, bf16_t* __restrict__ out) {
+    constexpr uint32_t SEG = MODE == 0 ? 2u : 3u;
+    const uint64_t total = n * (uint64_t)ldp;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ldp;
+        const uint32_t j = (uint32_t)(i - r * ldp);
+        const float x = j < ld ? in[r * ld + j] : 0.0f;
+        const bf16_t hi = f32_to_bf16_rne(x);
+        const bf16_t lo = f32_to_bf16_rne(x - bf16_to_f32(hi));
+        bf16_t* o = out + r * (uint64_t)(SEG * ldp) + (uint64_t)(j >> 6) * (SEG * 64) + (j & 63);
+        o[0] = hi;
+        o[64] = lo;
+        if (MODE == 1) o[128] = hi;
+    }
+}
+
+void launch_split_rows(const float* d_in, uint64_t n, uint32_t ld, uint32_t ldp, void* d_out, bool queries, hipStream_t s) {
+    if (!n) return;
+    const uint64_t work = n * (uint64_t)ldp;
+    uint64_t g = (work + 255) / 256;
+    if (g > 256ull * 16) g = 256ull * 16;
+    if (queries) split_rows_kernel<1><<<(unsigned)g, 256, 0, s>>>(d_in, n, ld, ldp, (bf16_t*)d_out);
+    else split_rows_kernel<0><<<(unsigned)g, 256, 0, s>>>(d_in, n, ld, ldp, (bf16_t*)d_out);
+}
+
 // ------------------------------------------------------------------ launchers
 static inline int grid_for(uint64_t work, int block, int cap = 256 * 8) {
     uint64_t g = (work + block - 1) / block;

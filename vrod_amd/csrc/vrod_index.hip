@@ -101,6 +101,7 @@ struct Pending {
     uint32_t* flags = nullptr;     // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits, [64..] pacing counters
     DevBuf q_raw, q_lp, scores, keys_a, keys_b, lists, small, hist, cand_rows, cand_fast, cand_canon;
     DevBuf q_f32;                  // prepared queries (the exact path re-reads them)
+    DevBuf q_planes;               // split pass: [nq_pad][3 * ldp] bf16, [hi_j | lo_j | hi_j] per K-tile j
     uint32_t* h_readback = nullptr;   // pinned host block: status[nq] + 4 scalars, one D2H per search
     size_t h_readback_words = 0;
     hipEvent_t done = nullptr;     // recorded behind the D2H
@@ -126,6 +127,14 @@ struct vrod_index {
     int path = VROD_PATH_AUTO;
     int profiling = 0;
     vrod_search_stats stats{};
+
+    // fp32 corpus, opt-in (VROD_F32_SPLIT=1 when the handle is created): bf16 planes [hi | lo] of
+    // the prepared rows for the batched fast pass on the bf16 matrix cores (kernels_prep.hip
+    // split_rows_kernel).  Built lazily for rows [0, planes_rows) at the next batched search.
+    bool split_enabled = false;
+    void* planes = nullptr;        // [planes_cap][2 * ldp] bf16, [hi_j | lo_j] per 64-element K-tile j
+    uint64_t planes_cap = 0, planes_rows = 0;
+    uint32_t ldp = 0;              // dim rounded up to 64 (bf16 128-B lines)
 
     // workspaces
     DevBuf raw_stage, nrm_ws, out_ids, out_scores;
@@ -172,6 +181,7 @@ static int index_reserve(vrod_index* idx, uint64_t n_rows) {
     HIP_TRY(hipStreamSynchronize(idx->stream));
     if (idx->corpus) (void)hipFree(idx->corpus);
     if (idx->xnorm2) (void)hipFree(idx->xnorm2);
+    if (idx->planes) { (void)hipFree(idx->planes); idx->planes = nullptr; idx->planes_cap = idx->planes_rows = 0; }   // rebuilt lazily
     idx->corpus = nc;
     idx->xnorm2 = nx;
     idx->capacity = want;
@@ -359,9 +369,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     P.t0 = tm.mark();
 
     const uint64_t N = idx->count;
-    const uint32_t kp = choose_kp(N, k);
-    st.kprime = kp;
-    P.N = N; P.kp = kp;
+    uint32_t kp = choose_kp(N, k);
 
     // ---- path
     int path = idx->path;
@@ -369,8 +377,19 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     // about one HBM pass per 8 queries (bf16: 0.63 / 0.69 / 2.0 ms at 1 / 4 / 8 queries, fp32:
     // 1.09 / 1.21 / 1.47 / 2.85 ms at 1 / 4 / 8 / 16); an MFMA batch costs the same for any
     // nq <= 256 (bf16 0.85 ms, fp32 5.97 ms: the fp32 MFMA rate is 16x lower).
+    // (opt-in split pass over an fp32 corpus: ~1.5 HBM passes + 3 bf16 MFMA products, cheaper
+    // than the stream scan from ~12 queries on)
+    const bool can_split = idx->split_enabled && idx->dtype == VROD_DTYPE_F32 && N > 0 &&
+                           (uint64_t)k + std::max<uint32_t>(32, k / 2) <= kSelectChunk / 2;
     if (path == VROD_PATH_AUTO)
-        path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 4u : 32u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
+        path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 4u : can_split ? 12u : 32u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
+    const bool split = can_split && path == VROD_PATH_MFMA;
+    if (split) {
+        // the split pass's certificate bound is ~3x the fp32 MFMA pass's: more candidates per query
+        kp = (uint32_t)std::min<uint64_t>(N, (uint64_t)k + std::max<uint32_t>(32, k / 2));
+    }
+    st.kprime = kp;
+    P.N = N; P.kp = kp;
     st.path = path;
     P.path = path;
 
@@ -499,6 +518,14 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         // (4) keep the best k' of every list.
         if (idx->metric == VROD_METRIC_COSINE) { eps_mode = 0; eps_c = 4.f * idx->dim * u; }
         else { eps_mode = 2; eps_c = 4.f * (idx->dim + 4) * u; }
+        if (split) {
+            // |fast - exact dot|: representation (x = hi + lo + r, |r| <= 2^-16 |x|, the lo.lo term
+            // dropped) <= 3.1 * 2^-16 |q||x|; fp32 accumulation of 3*dim exact bf16 products in any
+            // order <= 4.1 * 3*dim * 2^-24 |q||x|.  (L2 = |q|^2 + |x|^2 - 2 q.x on the same dot.)
+            const float repr = 3.1f * 1.52587890625e-5f;
+            if (idx->metric == VROD_METRIC_COSINE) eps_c = 4.1f * 3.f * idx->dim * u + repr;
+            else eps_c = 4.1f * (3.f * idx->dim + 4) * u + repr;
+        }
         // The MFMA scans own the whole chip.  The dense sample pass starts when the other slot's
         // last scan is through, the first filtered stage when that whole search is: the other
         // search's tail (compaction, re-score, certificate, read-back) then runs beside this
@@ -509,6 +536,29 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
         a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.metric = idx->metric;
+        int scan_dtype = idx->dtype;
+        if (split) {
+            // planes of the rows added since the last batched search, and of this batch's queries
+            if (idx->planes_cap < idx->capacity) {
+                if (idx->planes) { (void)hipFree(idx->planes); idx->planes = nullptr; idx->planes_cap = idx->planes_rows = 0; }
+                HIP_TRY(hipMalloc(&idx->planes, idx->capacity * 2ull * idx->ldp * 2ull));
+                idx->planes_cap = idx->capacity;
+            }
+            if (idx->planes_rows < N) {
+                launch_split_rows((const float*)idx->corpus + idx->planes_rows * idx->ld, N - idx->planes_rows, idx->ld, idx->ldp,
+                                  (char*)idx->planes + idx->planes_rows * 2ull * idx->ldp * 2ull, false, s);
+                if (round_up(N, kRowTile) > N)   // the tile padding rows stay zero
+                    HIP_TRY(hipMemsetAsync((char*)idx->planes + N * 2ull * idx->ldp * 2ull, 0, (round_up(N, kRowTile) - N) * 2ull * idx->ldp * 2ull, s));
+                idx->planes_rows = N;
+            }
+            VROD_TRY(P.q_planes.ensure((size_t)nq_pad * 3 * idx->ldp * 2));
+            launch_split_rows(P.q_f32.as<float>(), nq_pad, idx->ld, idx->ldp, P.q_planes.p, true, s);
+            a.corpus = idx->planes; a.queries = P.q_planes.p;
+            a.ld = 3 * idx->ldp;                          // K extent = query row
+            a.lda_bytes = 2 * idx->ldp * 2;               // corpus row [hi_j | lo_j] per K-tile
+            a.a_wrap = 1;                                 // SPLIT form of the kernel
+            scan_dtype = VROD_DTYPE_BF16;
+        }
         std::vector<uint64_t> bounds{N};
         if (N > cap) {
             const uint32_t nqb = nq_pad / 256;
@@ -521,7 +571,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
             d.pace = pace_base; d.pace_is_zero = true; ++pace_launch;
             size_t e0, e1;
             tm.arm(e0, e1);
-            launch_scan_mfma(d, idx->dtype, idx->num_cus, s);
+            launch_scan_mfma(d, scan_dtype, idx->num_cus, s);
             P.scan_pairs.push_back({e0, e1});
             st.scan_launches++;
             st.scan_bytes += (double)dense_ld * row_bytes_alg;
@@ -540,7 +590,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
                 ++pace_launch;
                 size_t e0, e1;
                 tm.arm(e0, e1);
-                launch_scan_mfma(a, idx->dtype, idx->num_cus, s);
+                launch_scan_mfma(a, scan_dtype, idx->num_cus, s);
                 P.scan_pairs.push_back({e0, e1});
                 st.scan_launches++;
                 st.scan_bytes += (double)(end - lo / kRowTile * kRowTile) * row_bytes_alg;
@@ -853,6 +903,8 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
     idx->esize = dtype == VROD_DTYPE_BF16 ? 2 : 4;
     // rows are padded to whole 128-B lines: 64 bf16 / 32 fp32 elements
     idx->ld = (uint32_t)round_up(dim, dtype == VROD_DTYPE_BF16 ? 64 : 32);
+    idx->ldp = (uint32_t)round_up(dim, 64);
+    { const char* e = getenv("VROD_F32_SPLIT"); idx->split_enabled = dtype == VROD_DTYPE_F32 && e && e[0] == '1'; }
     int rc = VROD_OK;
     do {
         if (hipSetDevice(dev) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipSetDevice failed"); break; }
@@ -897,6 +949,7 @@ int vrod_index_destroy(vrod_index* idx) {
         if (P.flags) (void)hipFree(P.flags);
         if (P.stream) (void)hipStreamDestroy(P.stream);
         P.q_f32.release();
+        P.q_planes.release();
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
         if (P.done) (void)hipEventDestroy(P.done);
         if (P.scans_done) (void)hipEventDestroy(P.scans_done);
@@ -904,6 +957,7 @@ int vrod_index_destroy(vrod_index* idx) {
     }
     if (idx->caller_ev) (void)hipEventDestroy(idx->caller_ev);
     if (idx->corpus) (void)hipFree(idx->corpus);
+    if (idx->planes) (void)hipFree(idx->planes);
     if (idx->xnorm2) (void)hipFree(idx->xnorm2);
     if (idx->flags) (void)hipFree(idx->flags);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);

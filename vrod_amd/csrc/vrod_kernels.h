@@ -26,6 +26,8 @@ struct QueryInit {
     uint32_t* zero_words2;   // a second range (the pacing counters of the coming scan launches)
     uint32_t n_zero_words2;
 };
+// bf16 split of fp32 rows: corpus rows -> [hi | lo] (2*ldp), query rows -> [hi | hi | lo] (3*ldp)
+void launch_split_rows(const float* d_in, uint64_t n, uint32_t ld, uint32_t ldp, void* d_out, bool queries, hipStream_t s);
 void launch_prep_queries(const float* d_in, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t ld, int metric,
                          int dtype, float* d_out_f32, void* d_out_bf16, float* d_qn2, uint32_t* d_bad_flag,
                          uint32_t* d_max_bits, const QueryInit& init, hipStream_t s);
@@ -137,8 +139,8 @@ struct MfmaScanArgs {
     uint32_t* counts;       // [nq_pad]
     uint32_t cap;
     uint32_t ld;            // elements per row (multiple of 64 bf16 / 32 f32): the K extent, and the query row stride
-    uint32_t lda_bytes;     // 0, or (bf16 4-wave kernel) the corpus row stride in bytes when it differs, with
-    uint32_t a_wrap;        // a_wrap = K-tiles after which a corpus row is walked again from its start
+    uint32_t lda_bytes;     // split-bf16 pass over fp32 rows (bf16 4-wave kernel, a_wrap != 0): the corpus row
+    uint32_t a_wrap;        // stride in bytes ([hi_j | lo_j] planes; the query rows are [hi_j | lo_j | hi_j])
     uint32_t nq_pad;
     uint32_t row_begin;     // appends are limited to rows [row_begin, row_end); the launch
     uint32_t row_end;       // starts at the 256-row tile containing row_begin
