@@ -383,7 +383,20 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
                            (uint64_t)k + std::max<uint32_t>(32, k / 2) <= kSelectChunk / 2;
     if (path == VROD_PATH_AUTO)
         path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 4u : can_split ? 12u : 32u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
-    const bool split = can_split && path == VROD_PATH_MFMA;
+    bool split = can_split && path == VROD_PATH_MFMA;
+    if (split && idx->planes_cap < idx->capacity) {
+        // the planes are a second copy of the corpus: without room for them the handle quietly
+        // keeps the fp32 pass
+        if (idx->planes) { (void)hipFree(idx->planes); idx->planes = nullptr; idx->planes_cap = idx->planes_rows = 0; }
+        if (hipMalloc(&idx->planes, idx->capacity * 2ull * idx->ldp * 2ull) == hipSuccess) {
+            idx->planes_cap = idx->capacity;
+        } else {
+            (void)hipGetLastError();
+            idx->planes = nullptr;
+            idx->split_enabled = false;
+            split = false;
+        }
+    }
     if (split) {
         // the split pass's certificate bound is ~3x the fp32 MFMA pass's: more candidates per query
         kp = (uint32_t)std::min<uint64_t>(N, (uint64_t)k + std::max<uint32_t>(32, k / 2));
@@ -539,11 +552,6 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         int scan_dtype = idx->dtype;
         if (split) {
             // planes of the rows added since the last batched search, and of this batch's queries
-            if (idx->planes_cap < idx->capacity) {
-                if (idx->planes) { (void)hipFree(idx->planes); idx->planes = nullptr; idx->planes_cap = idx->planes_rows = 0; }
-                HIP_TRY(hipMalloc(&idx->planes, idx->capacity * 2ull * idx->ldp * 2ull));
-                idx->planes_cap = idx->capacity;
-            }
             if (idx->planes_rows < N) {
                 launch_split_rows((const float*)idx->corpus + idx->planes_rows * idx->ld, N - idx->planes_rows, idx->ld, idx->ldp,
                                   (char*)idx->planes + idx->planes_rows * 2ull * idx->ldp * 2ull, false, s);
