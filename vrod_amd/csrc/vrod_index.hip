@@ -110,6 +110,24 @@ struct Pending {
     size_t ev_used = 0, t0 = 0, t1 = 0;
     std::vector<std::pair<size_t, size_t>> scan_pairs;
     vrod_search_stats st{};
+
+    // hipGraph replay of small, launch-bound searches (search_enqueue): the launches of a search
+    // whose every pointer and size equals the captured one are replayed as one graph launch
+    struct GraphKey {
+        const void *q = nullptr, *oi = nullptr, *os = nullptr, *corpus = nullptr, *xn = nullptr;
+        const void* bufs[12] = {};
+        uint64_t N = 0, id_offset = 0;
+        uint32_t nq = 0, k = 0;
+        int path = 0;
+        bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof *this) == 0; }
+    };
+    GraphKey gkey{};               // of the last search enqueued in this slot
+    bool gkey_valid = false;
+    hipGraphExec_t gexec = nullptr;   // captured for gkey_graph
+    GraphKey gkey_graph{};
+    bool graph_off = false;        // a capture failed once: this slot stays on plain launches
+    // what a replay must restore of the enqueue's host-side results
+    uint32_t g_kp = 0; int g_path = 0, g_eps_mode = 0; float g_eps_c = 0.f; vrod_search_stats g_st{};
 };
 
 // ------------------------------------------------------------------ the index
@@ -354,8 +372,8 @@ static StagePlan plan_stages(uint64_t N, uint32_t kp, uint32_t cap, uint32_t max
 
 // Enqueue one search into slot P: every launch up to the D2H of the status block.  Returns
 // without waiting for the device (except on the trivial empty-corpus case).
-static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_raw, uint32_t nq, uint32_t k,
-                          uint64_t* d_out_ids, float* d_out_scores) {
+static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queries_raw, uint32_t nq, uint32_t k,
+                               uint64_t* d_out_ids, float* d_out_scores, bool in_graph) {
     vrod_search_stats& st = P.st;
     st = vrod_search_stats{};
     st.nq = nq;
@@ -499,7 +517,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         uint32_t* d_cnt = d_hist + 8 * 4096;
         // one HBM-bound scan at a time (two would only share the bandwidth and stretch each
         // other); everything behind the scan overlaps the other slot's scan
-        {
+        if (!in_graph) {
             Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
             HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
         }
@@ -514,7 +532,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
                                P.q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, P.scores.as<float>(), score_ld,
                                d_hist, kp, s);
             P.scan_pairs.push_back({a, b});
-            if (q0 + 8 >= nq) HIP_TRY(hipEventRecord(P.scans_done, s));
+            if (q0 + 8 >= nq && !in_graph) HIP_TRY(hipEventRecord(P.scans_done, s));
             st.scan_launches++;
             st.scan_bytes += (double)N * row_bytes_alg;
             st.scan_flops += 2.0 * nqc * (double)N * idx->dim;
@@ -628,8 +646,87 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(P.h_readback, d_readback, ((size_t)nq + 4) * 4, hipMemcpyDeviceToHost, s));
     P.t1 = tm.mark();
-    HIP_TRY(hipEventRecord(P.done, s));
+    if (!in_graph) HIP_TRY(hipEventRecord(P.done, s));
     return VROD_OK;
+}
+
+// Small searches are launch-bound (10k x 128, one query: ~9 launches, 80 us, of which the kernels
+// are a fraction): when a slot sees the same search again -- same query / output pointers, sizes,
+// corpus and workspaces -- its launches are captured into a hipGraph on the third occurrence and
+// replayed as ONE graph launch from then on.  Only the stream path with a single scan pass over a
+// small corpus and with profiling off qualifies; anything else, and any capture failure, takes the
+// plain launches.
+static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_raw, uint32_t nq, uint32_t k,
+                          uint64_t* d_out_ids, float* d_out_scores) {
+    static const bool graphs_on = [] { const char* e = getenv("VROD_GRAPH"); return !e || e[0] != '0'; }();
+    const uint64_t N = idx->count;
+    int path = idx->path;
+    if (path == VROD_PATH_AUTO && nq <= 4) path = VROD_PATH_STREAM;
+    // (measured at 10k x 128, one query: a replay costs the HOST less -- 50 vs 65 us per search with two
+    // in flight -- but is no faster end to end than plain launches, 91 vs 82 us synchronous: only
+    // searches begun while another one is pending, i.e. host-bound pipelines, take it)
+    const bool graphable = graphs_on && !P.graph_off && idx->profiling == 0 && nq >= 1 && nq <= 8 && N > 0 && idx->n_pending() >= 1 &&
+                           path == VROD_PATH_STREAM && (double)N * idx->ld * idx->esize <= 64.0 * 1048576.0;
+    Pending::GraphKey key{};
+    if (graphable) {
+        key.q = d_queries_raw; key.oi = d_out_ids; key.os = d_out_scores; key.corpus = idx->corpus; key.xn = idx->xnorm2;
+        const void* bufs[12] = {P.q_f32.p, P.q_lp.p, P.small.p, P.hist.p, P.scores.p, P.keys_a.p, P.cand_rows.p, P.cand_fast.p,
+                                P.cand_canon.p, P.h_readback, P.flags, idx->max_xn2_bits};
+        memcpy(key.bufs, bufs, sizeof bufs);
+        key.N = N; key.id_offset = idx->id_offset; key.nq = nq; key.k = k; key.path = idx->path;
+    }
+    Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
+    hipStream_t s = P.stream;
+    if (graphable && P.gexec && P.gkey_graph == key) {
+        // ---- replay
+        P.st = P.g_st;
+        P.nq = nq; P.k = k; P.out_ids = d_out_ids; P.out_scores = d_out_scores;
+        P.trivial = false; P.ev_used = 0; P.t0 = P.t1 = 0; P.scan_pairs.clear();
+        P.N = N; P.kp = P.g_kp; P.path = P.g_path; P.eps_mode = P.g_eps_mode; P.eps_c = P.g_eps_c;
+        HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
+        HIP_TRY(hipGraphLaunch(P.gexec, s));
+        HIP_TRY(hipEventRecord(P.scans_done, s));
+        HIP_TRY(hipEventRecord(P.done, s));
+        return VROD_OK;
+    }
+    const bool capture = graphable && P.gkey_valid && P.gkey == key;   // seen before with these very buffers
+    if (capture) {
+        if (P.gexec) { (void)hipGraphExecDestroy(P.gexec); P.gexec = nullptr; }
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = search_enqueue_body(idx, P, d_queries_raw, nq, k, d_out_ids, d_out_scores, true);
+            hipGraph_t g = nullptr;
+            const hipError_t e1 = hipStreamEndCapture(s, &g);
+            hipError_t e2 = hipErrorUnknown;
+            if (rc == VROD_OK && e1 == hipSuccess && g) e2 = hipGraphInstantiate(&P.gexec, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (rc == VROD_OK && e1 == hipSuccess && e2 == hipSuccess) {
+                P.gkey_graph = key;
+                P.g_kp = P.kp; P.g_path = P.path; P.g_eps_mode = P.eps_mode; P.g_eps_c = P.eps_c; P.g_st = P.st;
+                HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
+                HIP_TRY(hipGraphLaunch(P.gexec, s));
+                HIP_TRY(hipEventRecord(P.scans_done, s));
+                HIP_TRY(hipEventRecord(P.done, s));
+                return VROD_OK;
+            }
+            (void)hipGetLastError();
+            if (P.gexec) { (void)hipGraphExecDestroy(P.gexec); P.gexec = nullptr; }
+        } else {
+            (void)hipGetLastError();
+        }
+        P.graph_off = true;   // nothing was launched: fall through to the plain launches
+    }
+    const int rc = search_enqueue_body(idx, P, d_queries_raw, nq, k, d_out_ids, d_out_scores, false);
+    if (graphable && rc == VROD_OK) {
+        // the key is taken AFTER the body: its ensure() calls may have moved a workspace
+        const void* bufs[12] = {P.q_f32.p, P.q_lp.p, P.small.p, P.hist.p, P.scores.p, P.keys_a.p, P.cand_rows.p, P.cand_fast.p,
+                                P.cand_canon.p, P.h_readback, P.flags, idx->max_xn2_bits};
+        memcpy(key.bufs, bufs, sizeof bufs);
+        P.gkey = key;
+        P.gkey_valid = true;
+    } else {
+        P.gkey_valid = false;
+    }
+    return rc;
 }
 
 // Complete the search in slot P: wait for its status block, then run the exact path for the
@@ -958,6 +1055,7 @@ int vrod_index_destroy(vrod_index* idx) {
         if (P.stream) (void)hipStreamDestroy(P.stream);
         P.q_f32.release();
         P.q_planes.release();
+        if (P.gexec) (void)hipGraphExecDestroy(P.gexec);
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
         if (P.done) (void)hipEventDestroy(P.done);
         if (P.scans_done) (void)hipEventDestroy(P.scans_done);
