@@ -304,3 +304,14 @@ def test_bf16_4wave_kernel_ktile_counts(va, oracle, dim, metric):
     rq = rng.standard_normal((nq, dim)).astype(np.float32)
     st = run_case(va, oracle, raw, rq, k, "bf16", metric, 2)
     assert st["path"] == 2 and st["scan_launches"] >= 2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_denormal_score_range_is_inside_the_bound(va, oracle, dtype):
+    """Squared distances around 1e-40 are denormal: rounding errors there are absolute (half a
+    denormal ulp each), not relative, and the certificate's bound carries a term for them."""
+    rng = np.random.default_rng(3)
+    raw = (rng.standard_normal((20000, 96)) * 1e-21).astype(np.float32)
+    rq = (rng.standard_normal((40, 96)) * 1e-21).astype(np.float32)
+    st = run_case(va, oracle, raw, rq, 10, dtype, "l2", 2)
+    assert st["max_fast_err"] <= st["eps_bound"], st

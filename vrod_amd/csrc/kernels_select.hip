@@ -463,9 +463,11 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
                 const float sk = key_to_score_rt(key_skey(kk), metric);
                 const float qn = __builtin_sqrtf(__uint_as_float(*max_qn2_bits));
                 const float xn = __builtin_sqrtf(__uint_as_float(*max_xn2_bits));
-                const float eps = eps_mode == 0 ? eps_c * qn * xn
-                                : eps_mode == 1 ? eps_c * __builtin_fabsf(t) + 1e-30f
-                                                : eps_c * (qn + xn) * (qn + xn);
+                // + eps_c * 2^-125 = ~4d roundings of half a denormal ulp (2^-150) each: in the
+                // denormal range (scores below 1e-38) a rounding error is absolute, not relative
+                const float eps = (eps_mode == 0 ? eps_c * qn * xn
+                                 : eps_mode == 1 ? eps_c * __builtin_fabsf(t) + 1e-30f
+                                                 : eps_c * (qn + xn) * (qn + xn)) + eps_c * 2.3509887e-38f;
                 ok = metric == M_COSINE ? (sk > t + eps) : (sk < t - eps);
             }
         }

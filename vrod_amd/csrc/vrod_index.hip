@@ -756,7 +756,8 @@ static int search_complete(vrod_index* idx, Pending& P) {
         memcpy(&qn2, &hflags[1], 4);
         memcpy(&xn2, &hmaxx, 4);
         const float qn = std::sqrt(qn2), xn = std::sqrt(xn2);
-        st.eps_bound = eps_mode == 0 ? eps_c * qn * xn : eps_mode == 1 ? eps_c /* relative */ : eps_c * (qn + xn) * (qn + xn);
+        st.eps_bound = (eps_mode == 0 ? eps_c * qn * xn : eps_mode == 1 ? eps_c /* relative */ : eps_c * (qn + xn) * (qn + xn)) +
+                       (eps_mode == 1 ? 0.f : eps_c * 2.3509887e-38f);   // + the absolute slack of the denormal range
     }
     if (hflags[0]) {  // NaN/Inf in the queries: whatever was computed is void (flag reset on device)
         idx->stats = st;
