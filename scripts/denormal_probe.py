@@ -5,7 +5,7 @@ import vrod_amd as va
 from oracle import oracle as O
 O.build()
 rng = np.random.default_rng(3)
-for scale in [1e-18, 1e-19, 3e-20, 1e-21]:
+for scale in [float(x) for x in (sys.argv[1:] or ["1e-18", "1e-19", "3e-20", "1e-21"])]:
     for dtype, split in [("f32", False), ("f32", True), ("bf16", False)]:
         for metric in ["l2", "cosine"]:
             os.environ["VROD_F32_SPLIT"] = "1" if split else "0"

@@ -315,3 +315,19 @@ def test_denormal_score_range_is_inside_the_bound(va, oracle, dtype):
     rq = (rng.standard_normal((40, 96)) * 1e-21).astype(np.float32)
     st = run_case(va, oracle, raw, rq, 10, dtype, "l2", 2)
     assert st["max_fast_err"] <= st["eps_bound"], st
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("scale", [1e18, 3e18, 1e19])
+def test_l2_distances_that_overflow_fp32(va, oracle, path, scale):
+    """Squared distances beyond FLT_MAX are +inf in the canonical chain too (ties -> smaller id).
+    The fast scores are inf / NaN there and T = +inf stops meaning "nothing was left out": the
+    certificate must refuse and the exact path must answer."""
+    rng = np.random.default_rng(11)
+    raw = (rng.standard_normal((9000, 96)) * scale).astype(np.float32)
+    raw[17] = 0.0                      # one row at a finite distance from the zero query
+    rq = (rng.standard_normal((5, 96)) * scale).astype(np.float32)
+    rq[0] = 0.0
+    st = run_case(va, oracle, raw, rq, 10, "f32", "l2", path)
+    if scale >= 3e18:                  # (1e18: distances ~1e38, still finite: the fast passes may certify)
+        assert st["fallback_queries"] == 5

@@ -453,7 +453,13 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
     if (threadIdx.x == 0) {
         const float t = T[q];
         bool ok;
-        if (t == worst_score(metric)) {
+        // norms so large that the bound itself overflows (squared L2 distances beyond FLT_MAX):
+        // fast scores are inf / NaN there and T = +inf no longer means "nothing was left out"
+        const float qn_ = __builtin_sqrtf(__uint_as_float(*max_qn2_bits)), xn_ = __builtin_sqrtf(__uint_as_float(*max_xn2_bits));
+        const float span = metric == M_COSINE ? qn_ * xn_ : (qn_ + xn_) * (qn_ + xn_);
+        if (!(span < 3.0e38f)) {
+            ok = false;
+        } else if (t == worst_score(metric)) {
             ok = true;  // every row of the shard was a candidate
         } else {
             const uint64_t kk = (k >= 1 && k <= np2) ? sorted[k - 1] : 0ull;
