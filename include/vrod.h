@@ -57,6 +57,7 @@ enum { VROD_METRIC_COSINE = 0, VROD_METRIC_L2 = 1 };
 
 #define VROD_ID_NONE UINT64_MAX
 #define VROD_MAX_K 3584u
+#define VROD_MAX_DIM 32768u   /* one prepared row (fp32) must fit in a work-group's LDS next to its tiles */
 
 /* Which fast pass vrod_search uses. AUTO picks by batch size and dtype. */
 enum { VROD_PATH_AUTO = 0, VROD_PATH_STREAM = 1, VROD_PATH_MFMA = 2, VROD_PATH_EXACT = 3 };

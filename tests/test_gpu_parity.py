@@ -331,3 +331,21 @@ def test_l2_distances_that_overflow_fp32(va, oracle, path, scale):
     st = run_case(va, oracle, raw, rq, 10, "f32", "l2", path)
     if scale >= 3e18:                  # (1e18: distances ~1e38, still finite: the fast passes may certify)
         assert st["fallback_queries"] == 5
+
+
+@pytest.mark.parametrize("dim", [4096, 12288, 32768])
+def test_long_rows_every_path(va, oracle, dim):
+    """A scan pass keeps its queries in LDS: 8 of them up to d = 4096, fewer for longer rows
+    (VROD_MAX_DIM = 32768: one fp32 row next to the tiles of the prepare / re-score kernels)."""
+    rng = np.random.default_rng(dim)
+    n = 2500 if dim <= 12288 else 700
+    raw = rng.standard_normal((n, dim)).astype(np.float32)
+    for dtype, metric, path, nq in (("f32", "l2", 1, 9), ("bf16", "cosine", 1, 3), ("f32", "cosine", 2, 9), ("bf16", "l2", 2, 9), ("f32", "cosine", 3, 1)):
+        rq = rng.standard_normal((nq, dim)).astype(np.float32)
+        run_case(va, oracle, raw, rq, 5, dtype, metric, path)
+
+
+def test_dim_beyond_the_limit_is_rejected(va):
+    with pytest.raises(va.VrodError) as e:
+        va.Index(32769, "f32", "cosine")
+    assert e.value.code == 1

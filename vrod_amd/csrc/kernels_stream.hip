@@ -60,6 +60,15 @@ __device__ __forceinline__ float unit_accumulate(float acc, const typename Unit<
 // score key (sign, exponent, leading mantissa bits).  Smaller for more queries (LDS).
 template <int NQ> struct StreamHist { static constexpr int HB = NQ <= 2 ? 12 : (NQ == 4 ? 11 : 10); };
 int stream_hist_bits(int nq_pad) { return nq_pad <= 2 ? 12 : (nq_pad == 4 ? 11 : 10); }
+// Queries a scan pass can hold in LDS next to its histograms (160 KB per work-group): 8 up to
+// d = 4096, fewer for longer rows, 0 when not even one fits (d > ~36k floats).
+int stream_max_queries_per_pass(uint32_t ld) {
+    for (int nq = 8; nq >= 1; nq >>= 1) {
+        const size_t lds = (size_t)nq * ld * sizeof(float) + (size_t)nq * (sizeof(uint32_t) << stream_hist_bits(nq)) + 32;
+        if (lds <= 160 * 1024) return nq;
+    }
+    return 0;
+}
 
 // IT > 0: loads per lane per row known at compile time, UNROLL row-steps in flight.
 // IT == 0: runtime `it` (any ld), one row-step at a time.

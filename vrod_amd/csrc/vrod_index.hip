@@ -521,8 +521,9 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
             HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
         }
-        for (uint32_t q0 = 0; q0 < nq; q0 += 8) {
-            const int nqc = (int)std::min<uint32_t>(8, nq - q0);
+        const uint32_t qpp = (uint32_t)stream_max_queries_per_pass(idx->ld);   // queries per pass: 8, fewer for long rows
+        for (uint32_t q0 = 0; q0 < nq; q0 += qpp) {
+            const int nqc = (int)std::min<uint32_t>(qpp, nq - q0);
             int nqp = 1;
             while (nqp < nqc) nqp <<= 1;
             if (q0 > 0) HIP_TRY(hipMemsetAsync(d_hist, 0, hist_words * 4, s));
@@ -532,7 +533,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
                                P.q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, P.scores.as<float>(), score_ld,
                                d_hist, kp, s);
             P.scan_pairs.push_back({a, b});
-            if (q0 + 8 >= nq && !in_graph) HIP_TRY(hipEventRecord(P.scans_done, s));
+            if (q0 + qpp >= nq && !in_graph) HIP_TRY(hipEventRecord(P.scans_done, s));
             st.scan_launches++;
             st.scan_bytes += (double)N * row_bytes_alg;
             st.scan_flops += 2.0 * nqc * (double)N * idx->dim;
@@ -970,7 +971,7 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
                       int n_devices) {
     if (!out) return fail(VROD_ERR_INVALID_ARG, "out is null");
     *out = nullptr;
-    if (dim == 0 || dim > 65536) return fail(VROD_ERR_INVALID_ARG, "dim must be in 1..65536");
+    if (dim == 0 || dim > VROD_MAX_DIM) return fail(VROD_ERR_INVALID_ARG, "dim must be in 1..%u", VROD_MAX_DIM);
     if (dtype != VROD_DTYPE_F32 && dtype != VROD_DTYPE_BF16) return fail(VROD_ERR_INVALID_ARG, "bad dtype %d", dtype);
     if (metric != VROD_METRIC_COSINE && metric != VROD_METRIC_L2) return fail(VROD_ERR_INVALID_ARG, "bad metric %d", metric);
     if (n_devices < 0 || (n_devices > 0 && !device_ids)) return fail(VROD_ERR_INVALID_ARG, "bad device list");

@@ -51,6 +51,7 @@ void launch_scan_stream(const void* d_corpus, int dtype, int metric, uint32_t ld
                         const float* d_q, int nq_pad, float* d_scores, uint64_t score_ld,
                         uint32_t* d_hist, uint32_t kp, hipStream_t s);
 int stream_hist_bits(int nq_pad);
+int stream_max_queries_per_pass(uint32_t ld);   // 8 .. 1 by LDS capacity, 0: the row does not fit
 // Radix-select step 2: find the histogram bin holding the kp-th best score, then compact
 // every row whose key falls in that bin or a better one into d_keys[q][...] (composite keys,
 // unordered), counting into d_cnt[q].  More than `cap` such rows -> d_status[q] bit 1.
