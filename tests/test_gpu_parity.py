@@ -345,6 +345,45 @@ def test_long_rows_every_path(va, oracle, dim):
         run_case(va, oracle, raw, rq, 5, dtype, metric, path)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_exact_path_batches_its_queries(va, oracle, dtype, metric):
+    """The exact path walks the corpus once per group of 8 / 4 / 2 / 1 uncertified queries
+    (15 = one group of each size); rows and dims off every tile boundary."""
+    rng = np.random.default_rng(77)
+    raw = rng.standard_normal((9001, 203)).astype(np.float32)
+    rq = rng.standard_normal((15, 203)).astype(np.float32)
+    st = run_case(va, oracle, raw, rq, 33, dtype, metric, 3)
+    assert st["fallback_queries"] == 15
+
+
+def test_exact_path_groups_of_scattered_failures(va, oracle):
+    """Only some queries of a batch fail their certificate (those aimed at a block of > k'
+    identical rows): the groups of the exact path gather non-adjacent query rows."""
+    rng = np.random.default_rng(78)
+    base = rng.standard_normal((3000, 64)).astype(np.float32)
+    dup = np.repeat(rng.standard_normal((1, 64)).astype(np.float32), 200, axis=0)
+    raw = np.concatenate([base[:1500], dup, base[1500:]])
+    rq = rng.standard_normal((21, 64)).astype(np.float32)
+    hit = [0, 3, 4, 9, 10, 11, 17, 20]
+    rq[hit] = dup[0] + 0.01 * rng.standard_normal((len(hit), 64)).astype(np.float32)
+    for path in (1, 2):
+        st = run_case(va, oracle, raw, rq, 20, "f32", "cosine", path)
+        assert st["fallback_queries"] == len(hit)
+
+
+def test_exact_path_long_rows_fewer_queries_per_pass(va, oracle):
+    """d = 12288: two fp32 query rows no longer fit beside the staging tile in 64 KB of LDS,
+    so a pass of the exact path takes one query."""
+    rng = np.random.default_rng(79)
+    raw = rng.standard_normal((700, 12288)).astype(np.float32)
+    rq = rng.standard_normal((3, 12288)).astype(np.float32)
+    run_case(va, oracle, raw, rq, 5, "bf16", "l2", 3)
+    raw = rng.standard_normal((900, 3000)).astype(np.float32)   # 4 rows of 3008 floats fit, 8 do not
+    rq = rng.standard_normal((7, 3000)).astype(np.float32)
+    run_case(va, oracle, raw, rq, 5, "f32", "cosine", 3)
+
+
 def test_dim_beyond_the_limit_is_rejected(va):
     with pytest.raises(va.VrodError) as e:
         va.Index(32769, "f32", "cosine")

@@ -765,19 +765,34 @@ static int search_complete(vrod_index* idx, Pending& P) {
         return fail(VROD_ERR_INVALID_VALUE, "queries contain NaN or Inf");
     }
 
-    // -------- exact path for uncertified queries: canonical score of every row, exact select
-    for (uint32_t qi = 0; qi < nq; ++qi) {
-        if (!hstatus[qi]) continue;
-        st.fallback_queries++;
+    // -------- exact path for uncertified queries: canonical score of every row, exact select.
+    // Up to 8 queries share one pass over the corpus (their add chains are independent, so the
+    // pass costs little more than one query's); the score block is kept under 1 GiB.
+    std::vector<uint32_t> failed;
+    for (uint32_t qi = 0; qi < nq; ++qi)
+        if (hstatus[qi]) failed.push_back(qi);
+    st.fallback_queries = (uint32_t)failed.size();
+    if (!failed.empty()) {
         const uint64_t score_ld = round_up(N, 64);
-        VROD_TRY(P.scores.ensure((size_t)score_ld * 4));
-        launch_rescore_all(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.q_f32.as<float>() + (size_t)qi * idx->ld, N,
-                           P.scores.as<float>(), s);
+        int gmax = rescore_all_max_queries(idx->ld);
+        while (gmax > 1 && (uint64_t)gmax * score_ld * 4 > (1ull << 30)) gmax >>= 1;
         const uint32_t kx = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(k, N), kSelectChunk / 2);
-        const uint64_t* keys; uint64_t kld, kn;
-        VROD_TRY(select_chain(idx, P, P.scores.as<float>(), score_ld, N, 1, kx, &keys, &kld, &kn));
-        launch_keys_to_output(keys, kn, idx->metric, k, idx->id_offset, P.out_ids + (size_t)qi * k, P.out_scores + (size_t)qi * k, s);
-        HIP_TRY(hipGetLastError());
+        for (size_t f0 = 0; f0 < failed.size();) {
+            int g = gmax;
+            while ((size_t)g > failed.size() - f0) g >>= 1;
+            VROD_TRY(P.scores.ensure((size_t)g * score_ld * 4));
+            launch_rescore_all(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.q_f32.as<float>(), &failed[f0], g, N,
+                               P.scores.as<float>(), score_ld, s);
+            const uint64_t* keys; uint64_t kld, kn;
+            VROD_TRY(select_chain(idx, P, P.scores.as<float>(), score_ld, N, g, kx, &keys, &kld, &kn));
+            for (int i = 0; i < g; ++i) {
+                const uint32_t qi = failed[f0 + i];
+                launch_keys_to_output(keys + (size_t)i * kld, kn, idx->metric, k, idx->id_offset, P.out_ids + (size_t)qi * k,
+                                      P.out_scores + (size_t)qi * k, s);
+            }
+            HIP_TRY(hipGetLastError());
+            f0 += g;
+        }
     }
     if (st.fallback_queries) {
         P.t1 = tm.mark();

@@ -119,9 +119,13 @@ void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores,
 void launch_rescore_candidates(const void* d_corpus, int dtype, int metric, uint32_t dim,
                                uint32_t ld, const float* d_q, int nq, const uint32_t* d_cand_rows,
                                uint32_t kp, float* d_out, hipStream_t s);
-// All rows of the shard for ONE query: out[nrows].
+// All rows of the shard for nq in {1, 2, 4, 8} queries in ONE pass over the corpus (the exact
+// path): query n is row query_index[n] of d_q; out[n * out_ld + row].  nq must not exceed
+// rescore_all_max_queries(ld) (LDS: nq query rows beside the staging tile).
+int rescore_all_max_queries(uint32_t ld);
 void launch_rescore_all(const void* d_corpus, int dtype, int metric, uint32_t dim, uint32_t ld,
-                        const float* d_q1, uint64_t nrows, float* d_out, hipStream_t s);
+                        const float* d_q, const uint32_t* query_index, int nq, uint64_t nrows,
+                        float* d_out, uint64_t out_ld, hipStream_t s);
 
 // ---- kernels_mfma.hip : batched Q.K^T scan with fused threshold filter
 // Timing of the dominant scan launches without marker packets: the launcher of the next scan
