@@ -81,7 +81,7 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         gathered = torch.empty(world * bufs[0][0].numel(), dtype=torch.uint8, device=dev)
         mi = torch.empty((nq, k), dtype=torch.int64, device=dev)
         ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, max_err=0.0, eps=0.0)
+    acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, max_err=0.0, eps=0.0, split=0)
 
     def begin(s):
         _, oi, osc = bufs[s % depth]
@@ -106,6 +106,7 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         acc["scan_bytes"] += st["scan_bytes"]
         acc["launches"] += st["scan_launches"]
         acc["fallback"] += st["fallback_queries"]
+        acc["split"] += st["split_pass"]
         acc["max_err"] = max(acc["max_err"], st["max_fast_err"])
         acc["eps"] = st["eps_bound"]
     final = (mi, ms) if collective else (bufs[(steps - 1) % depth][1], bufs[(steps - 1) % depth][2])
@@ -261,9 +262,12 @@ def main():
             per_launch = acc["scan_bytes"] / max(acc["launches"], 1)
             work_key = "algorithmic_bytes_per_launch"
         else:
-            # VROD_F32_SPLIT=1: an fp32 corpus scanned as three bf16 products (hi.hi + hi.lo + lo.hi) on the
-            # bf16 matrix cores: the kernel executes 3x the algorithmic flops, priced against the bf16 peak
-            split = wl["dtype"] == "f32" and os.environ.get("VROD_F32_SPLIT") == "1"
+            # split pass (the default for fp32 batches while memory allows, VROD_F32_SPLIT=0 switches it off):
+            # an fp32 corpus scanned as three bf16 products (hi.hi + hi.lo + lo.hi) on the bf16 matrix cores:
+            # the kernel executes 3x the algorithmic flops, priced against the bf16 peak
+            split = acc["split"] > 0
+            if split and acc["split"] != args.steps:
+                raise SystemExit("bench: the fast pass changed between timed batches (split pass switched off mid-run)")
             factor = 3.0 if split else 1.0
             achieved = factor * acc["scan_flops"] / (acc["scan_ms"] * 1e-3) / 1e12 if acc["scan_ms"] else 0.0
             peak, unit = PEAK["mfma_bf16" if wl["dtype"] == "bf16" or split else "mfma_f32"]

@@ -35,6 +35,9 @@ pub struct vrod_search_stats {
     pub scan_flops: f64,
     pub max_fast_err: f32,
     pub eps_bound: f32,
+    /// 1: the batched fast pass of an F32 handle ran on its bf16 [hi | lo] planes
+    pub split_pass: u32,
+    pub reserved_: u32,
 }
 
 extern "C" {

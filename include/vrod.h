@@ -75,6 +75,8 @@ typedef struct {
     float max_fast_err;         /* max |fast - canonical| over re-scored candidates (relative to
                                  * |canonical| on the direct-L2 stream path, whose bound is relative) */
     float eps_bound;            /* the certificate's bound on that error */
+    uint32_t split_pass;        /* 1: the batched fast pass of an F32 handle ran on its bf16 [hi | lo] planes */
+    uint32_t reserved_;
 } vrod_search_stats;
 
 /* --- lifecycle ------------------------------------------------------------- */
@@ -147,10 +149,14 @@ int vrod_merge_topk_packed_device(int device, int metric, const void *d_packed, 
                                   float *d_out_scores, void *stream);
 
 /* --- knobs & introspection --------------------------------------------------
- * Environment, read when a handle is created: VROD_F32_SPLIT=1 -- an F32 handle keeps bf16
- * [hi | lo] planes of its rows (a second copy of the corpus) and runs batched searches as three
- * bf16 matrix-core products instead of one fp32 one (2.5x faster at 10M x 1536, batch 256); the
- * results are the same bits: only the fast pass and the certificate's bound change. */
+ * Environment, read when a handle is created: VROD_F32_SPLIT.  An F32 handle keeps bf16
+ * [hi | lo] planes of its rows (a second copy of the corpus, built at the first batched search)
+ * and runs batched searches as three bf16 matrix-core products instead of one fp32 one (2.5x
+ * faster at 10M x 1536, batch 256); the results are the same bits: only the fast pass and the
+ * certificate's bound change.  Default: on while the planes leave max(1/8 of the device, 4 GiB)
+ * free, and switched off for the handle after two searches in which more than 1/8 of the queries
+ * failed the (wider) certificate.  =0: never.  =1: always (no margin check, never switched off).
+ * If the planes cannot be allocated the handle quietly keeps the fp32 pass. */
 int vrod_index_set_path(vrod_index *idx, int path);      /* VROD_PATH_* (default AUTO) */
 int vrod_index_set_profiling(vrod_index *idx, int on);   /* 1: scan_ms (events attached to the scan dispatches), 2: + total_ms (stream markers) */
 int vrod_index_last_stats(const vrod_index *idx, vrod_search_stats *out);

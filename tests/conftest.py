@@ -17,3 +17,24 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def f32_split(mode):
+    """VROD_F32_SPLIT for the handles created inside: "0" = fp32 MFMA pass, "1" = bf16 split
+    pass forced, None = the library's default (split while memory allows)."""
+    old = os.environ.get("VROD_F32_SPLIT")
+    if mode is None:
+        os.environ.pop("VROD_F32_SPLIT", None)
+    else:
+        os.environ["VROD_F32_SPLIT"] = mode
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("VROD_F32_SPLIT", None)
+        else:
+            os.environ["VROD_F32_SPLIT"] = old

@@ -32,14 +32,21 @@ def assert_same(ids, sc, oi, osc, what=""):
 
 
 def run_case(va, O, raw, rq, k, dtype, metric, path, id_offset=0):
-    with va.Index(raw.shape[1], dtype, metric) as ix:
-        ix.add(raw)
-        ix.set_id_offset(id_offset)
-        ix.set_path(path)
-        ids, sc = ix.search(rq, k)
-        st = ix.last_stats()
+    from conftest import f32_split
     oi, osc = O.search(raw, rq, k, DT[dtype], ME[metric], id_offset=id_offset)
-    assert_same(ids, sc, oi, osc, f"{dtype}/{metric}/path{path}")
+    # a batched search over an fp32 corpus has two fast passes (the fp32 MFMA kernel, and by default
+    # the bf16 split pass over [hi | lo] planes): both must give the oracle's bits
+    modes = ("0", None) if dtype == "f32" and path in (0, 2) and rq.shape[0] > 12 else (None,)
+    for mode in modes:
+        with f32_split(mode), va.Index(raw.shape[1], dtype, metric) as ix:
+            ix.add(raw)
+            ix.set_id_offset(id_offset)
+            ix.set_path(path)
+            ids, sc = ix.search(rq, k)
+            st = ix.last_stats()
+        assert_same(ids, sc, oi, osc, f"{dtype}/{metric}/path{path}/split={mode}")
+        if mode == "0":
+            assert st["split_pass"] == 0
     return st
 
 

@@ -46,20 +46,28 @@ def pipelined(ix, torch, batches, k):
     return res
 
 
-@pytest.mark.parametrize("dtype,metric,path,nq", [("bf16", "cosine", 2, 300), ("f32", "l2", 1, 3),
-                                                  ("f32", "cosine", 2, 40), ("bf16", "l2", 1, 8), ("f32", "cosine", 3, 2)])
-def test_pipelined_equals_sequential_and_oracle(va, oracle, dtype, metric, path, nq):
+@pytest.mark.parametrize("dtype,metric,path,nq,split", [("bf16", "cosine", 2, 300, None), ("f32", "l2", 1, 3, None),
+                                                        ("f32", "cosine", 2, 40, "0"), ("f32", "cosine", 2, 40, None),
+                                                        ("bf16", "l2", 1, 8, None), ("f32", "cosine", 3, 2, None)])
+def test_pipelined_equals_sequential_and_oracle(va, oracle, dtype, metric, path, nq, split):
     import torch
+    from conftest import f32_split
     raw = oracle.synth_rows(1, 0, 30000, 256, threads=8)
     # batches of different sizes: slot buffers regrow while the other slot is in flight
     sizes = [nq, max(1, nq // 2), nq + 5, nq]
     batches = [oracle.synth_rows(2, 1000 * i, n, 256) for i, n in enumerate(sizes)]
     k = 10
-    with va.Index(256, dtype, metric) as ix:
+    with f32_split(split), va.Index(256, dtype, metric) as ix:
         ix.add(raw)
         ix.set_path(path)
         seq = [ix.search(b, k) for b in batches]
         pip = pipelined(ix, torch, batches, k)
+    with f32_split(split), va.Index(256, dtype, metric) as ix:
+        ix.add(raw)
+        ix.set_path(path)
+        pip_first = pipelined(ix, torch, batches, k)   # an fp32 handle builds its bf16 planes inside the first pipelined batch
+    for a, b in zip(pip, pip_first):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
     for i, b in enumerate(batches):
         oi, osc = oracle.search(raw, b, k, DT[dtype], ME[metric])
         ids, sc, st = pip[i]

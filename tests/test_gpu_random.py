@@ -50,7 +50,8 @@ def test_random_case_matches_oracle(va, oracle, case):
     rq = (rng.standard_normal((nq, dim)) * scale).astype(np.float32)
     if dup:
         rq[0] = raw[0]                             # a query equal to a stored (duplicated) row
-    with va.Index(dim, dtype, metric) as ix:
+    from conftest import f32_split
+    with f32_split([None, "0", "1"][i % 3]), va.Index(dim, dtype, metric) as ix:   # fp32 batches: default / fp32 MFMA / forced split
         ix.add(raw)
         ix.set_path(path)
         ids, sc = ix.search(rq, k)

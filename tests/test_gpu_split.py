@@ -1,5 +1,5 @@
-"""Opt-in split pass for fp32 corpora (VROD_F32_SPLIT=1 at handle creation): the batched fast
-pass runs on the bf16 matrix cores over [hi | lo] planes of the fp32 rows (q.x ~ hi.hi + hi.lo +
+"""Split pass for fp32 corpora (default while memory allows; VROD_F32_SPLIT=0 / 1 at handle creation
+switch it off / force it): the batched fast pass runs on the bf16 matrix cores over [hi | lo] planes of the fp32 rows (q.x ~ hi.hi + hi.lo +
 lo.hi).  Only the fast pass changes: candidates are re-scored canonically and certified against a
 bound that covers the representation error, so ids and score bits must still be the oracle's.
 """
@@ -49,7 +49,7 @@ def test_split_pass_is_bit_exact(va, oracle, split_env, metric, dim, nq, k):
         ix.add(raw[20000:])                       # ... and extended lazily at the next batched search
         ids, sc = ix.search(rq, k)
         st = ix.last_stats()
-    assert st["path"] == 2, "AUTO must route a batch of >= 13 queries to the MFMA (split) pass"
+    assert st["path"] == 2 and st["split_pass"] == 1, "AUTO must route a batch of >= 13 queries to the MFMA (split) pass"
     assert st["kprime"] == min(n, k + max(32, k // 2))
     oi, osc = oracle.search(raw, rq, k, 0, ME[metric])
     assert np.array_equal(ids, oi), np.argwhere(ids != oi)[:5]
@@ -61,19 +61,62 @@ def test_split_pass_is_bit_exact(va, oracle, split_env, metric, dim, nq, k):
         assert st["fallback_queries"] <= nq // 10, st   #  the largest norm and many queries take the exact path)
 
 
-def test_split_is_off_by_default_and_for_small_batches(va, oracle, split_env):
+def test_split_is_the_default_but_not_for_small_batches_or_when_switched_off(va, oracle):
+    from conftest import f32_split
     raw = oracle.synth_rows(1, 0, 20000, 96)
-    rq = oracle.synth_rows(2, 0, 8, 96)
-    with va.Index(96, "f32", "cosine") as ix:
-        ix.add(raw)
-        ix.search(rq, 10)
-        assert ix.last_stats()["path"] == 1          # 8 queries: the stream scan, split or not
-    os.environ["VROD_F32_SPLIT"] = "0"
+    rq8 = oracle.synth_rows(2, 0, 8, 96)
     rq = oracle.synth_rows(2, 0, 40, 96)
-    with va.Index(96, "f32", "cosine") as ix:
+    oi, osc = oracle.search(raw, rq, 10, 0, 0)
+    with f32_split(None), va.Index(96, "f32", "cosine") as ix:
+        ix.add(raw)
+        ix.search(rq8, 10)
+        assert ix.last_stats()["path"] == 1          # 8 queries: the stream scan, split or not
+        assert ix.last_stats()["split_pass"] == 0
+        ids, sc = ix.search(rq, 10)
+        st = ix.last_stats()
+        assert st["path"] == 2 and st["split_pass"] == 1 and st["kprime"] == 10 + 32
+        assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))
+    with f32_split("0"), va.Index(96, "f32", "cosine") as ix:
         ix.add(raw)
         ids, sc = ix.search(rq, 10)
         st = ix.last_stats()
-    assert st["path"] == 2 and st["kprime"] == 10 + 16   # the fp32 MFMA pass and its k'
-    oi, osc = oracle.search(raw, rq, 10, 0, 0)
+    assert st["path"] == 2 and st["split_pass"] == 0 and st["kprime"] == 10 + 16   # the fp32 MFMA pass and its k'
     assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))
+    with f32_split(None), va.Index(96, "bf16", "cosine") as ix:      # bf16 handles have no planes
+        ix.add(raw)
+        ix.search(rq, 10)
+        assert ix.last_stats()["split_pass"] == 0
+
+
+def test_default_split_is_switched_off_by_a_corpus_it_cannot_certify(va, oracle):
+    """Rows whose squared distances from the query climb by 3e-6 of the largest one per rank: the
+    gap k .. k' is wider than the fp32 pass's bound (3.2e-5 of it over 16 ranks) and narrower than
+    the split pass's (1.4e-4 over 32).  Every query fails the split certificate, and after two such
+    searches the handle goes back to the fp32 pass (and gives the planes back).  Forced (=1) it
+    never does.  Results are the oracle's bits throughout."""
+    from conftest import f32_split
+    rng = np.random.default_rng(5)
+    n, dim, nq, k = 30000, 128, 48, 10
+    u = rng.standard_normal((n, dim))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    d2 = 0.9 + 3e-6 * rng.permutation(n)
+    raw = (u * np.sqrt(d2)[:, None]).astype(np.float32)
+    rq = np.zeros((nq, dim), dtype=np.float32)
+    oi, osc = oracle.search(raw, rq, k, 0, 1)
+    seen = []
+    with f32_split(None), va.Index(dim, "f32", "l2") as ix:
+        ix.add(raw)
+        for _ in range(4):
+            ids, sc = ix.search(rq, k)
+            st = ix.last_stats()
+            seen.append((st["split_pass"], st["fallback_queries"]))
+            assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))
+    assert seen[0][0] == 1 and seen[0][1] * 8 > nq, f"the case is meant to defeat the split bound: {seen}"
+    assert [s[0] for s in seen] == [1, 1, 0, 0], seen
+    assert seen[3][1] * 8 <= nq, f"the fp32 pass certifies what the split pass could not: {seen}"
+    with f32_split("1"), va.Index(dim, "f32", "l2") as ix:
+        ix.add(raw)
+        for _ in range(3):
+            ids, sc = ix.search(rq, k)
+            assert ix.last_stats()["split_pass"] == 1
+            assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))

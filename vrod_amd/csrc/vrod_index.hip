@@ -90,6 +90,7 @@ struct Pending {
     bool trivial = false;          // nq == 0 or empty corpus: the outputs are already final
     uint32_t nq = 0, k = 0, kp = 0;
     int path = 0, eps_mode = 0;
+    bool split = false;            // the fast pass of this search ran on the bf16 planes
     float eps_c = 0.f;
     uint64_t N = 0;
     uint64_t* out_ids = nullptr;
@@ -146,10 +147,13 @@ struct vrod_index {
     int profiling = 0;
     vrod_search_stats stats{};
 
-    // fp32 corpus, opt-in (VROD_F32_SPLIT=1 when the handle is created): bf16 planes [hi | lo] of
-    // the prepared rows for the batched fast pass on the bf16 matrix cores (kernels_prep.hip
-    // split_rows_kernel).  Built lazily for rows [0, planes_rows) at the next batched search.
+    // fp32 corpus: bf16 planes [hi | lo] of the prepared rows for the batched fast pass on the bf16
+    // matrix cores (kernels_prep.hip split_rows_kernel), a second copy of the corpus.  Built lazily
+    // for rows [0, planes_rows) at the next batched search, on by default while the device keeps a
+    // margin of free memory beside them (VROD_F32_SPLIT=0: never, =1: always try).
     bool split_enabled = false;
+    bool split_forced = false;     // VROD_F32_SPLIT=1: no memory-margin check, never switched off by the failure count
+    uint32_t split_bad = 0;        // split searches that sent more than 1/8 of their queries to the exact path
     void* planes = nullptr;        // [planes_cap][2 * ldp] bf16, [hi_j | lo_j] per 64-element K-tile j
     uint64_t planes_cap = 0, planes_rows = 0;
     uint32_t ldp = 0;              // dim rounded up to 64 (bf16 128-B lines)
@@ -406,7 +410,14 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         // the planes are a second copy of the corpus: without room for them the handle quietly
         // keeps the fp32 pass
         if (idx->planes) { (void)hipFree(idx->planes); idx->planes = nullptr; idx->planes_cap = idx->planes_rows = 0; }
-        if (hipMalloc(&idx->planes, idx->capacity * 2ull * idx->ldp * 2ull) == hipSuccess) {
+        const size_t want = idx->capacity * 2ull * idx->ldp * 2ull;
+        bool room = true;
+        if (!idx->split_forced) {
+            // by default the planes must leave the caller a margin: 1/8 of the device or 4 GiB
+            size_t free_b = 0, total_b = 0;
+            room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= want + std::max<size_t>(total_b / 8, (size_t)4 << 30);
+        }
+        if (room && hipMalloc(&idx->planes, want) == hipSuccess) {
             idx->planes_cap = idx->capacity;
         } else {
             (void)hipGetLastError();
@@ -415,6 +426,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             split = false;
         }
     }
+    P.split = split;
     if (split) {
         // the split pass's certificate bound is ~3x the fp32 MFMA pass's: more candidates per query
         kp = (uint32_t)std::min<uint64_t>(N, (uint64_t)k + std::max<uint32_t>(32, k / 2));
@@ -422,6 +434,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     st.kprime = kp;
     P.N = N; P.kp = kp;
     st.path = path;
+    st.split_pass = split ? 1u : 0u;
     P.path = path;
 
     if (N == 0) {  // empty corpus: every slot unfilled
@@ -683,7 +696,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         P.st = P.g_st;
         P.nq = nq; P.k = k; P.out_ids = d_out_ids; P.out_scores = d_out_scores;
         P.trivial = false; P.ev_used = 0; P.t0 = P.t1 = 0; P.scan_pairs.clear();
-        P.N = N; P.kp = P.g_kp; P.path = P.g_path; P.eps_mode = P.g_eps_mode; P.eps_c = P.g_eps_c;
+        P.N = N; P.kp = P.g_kp; P.path = P.g_path; P.eps_mode = P.g_eps_mode; P.eps_c = P.g_eps_c; P.split = false;
         HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
         HIP_TRY(hipGraphLaunch(P.gexec, s));
         HIP_TRY(hipEventRecord(P.scans_done, s));
@@ -772,6 +785,12 @@ static int search_complete(vrod_index* idx, Pending& P) {
     for (uint32_t qi = 0; qi < nq; ++qi)
         if (hstatus[qi]) failed.push_back(qi);
     st.fallback_queries = (uint32_t)failed.size();
+    if (P.split && failed.size() * 8 > nq && !idx->split_forced && ++idx->split_bad >= 2) {
+        // the split pass's bound is ~3x wider than the fp32 pass's: on a corpus whose gaps sit
+        // inside it (twice now) the fp32 pass is the better fast pass.  The planes are released by
+        // the next search that finds the handle idle.
+        idx->split_enabled = false;
+    }
     if (!failed.empty()) {
         const uint64_t score_ld = round_up(N, 64);
         int gmax = rescore_all_max_queries(idx->ld);
@@ -811,6 +830,11 @@ static int search_begin(vrod_index* idx, const float* d_queries_raw, uint32_t nq
                         uint64_t* d_out_ids, float* d_out_scores) {
     if (idx->n_pending() >= 2) return fail(VROD_ERR_INVALID_ARG, "two searches are already pending: call vrod_search_end first");
     Pending& P = idx->slot[idx->n_begun & 1];
+    if (idx->planes && !idx->split_enabled && idx->n_pending() == 0) {   // split pass switched off: give the planes back
+        (void)hipFree(idx->planes);
+        idx->planes = nullptr;
+        idx->planes_cap = idx->planes_rows = 0;
+    }
     int rc = search_enqueue(idx, P, d_queries_raw, nq, k, d_out_ids, d_out_scores);
     if (rc != VROD_OK) {
         // a half-enqueued search: drain the stream, consume the bad-value flag, leave the slot free
@@ -945,6 +969,7 @@ static int composite_search(vrod_index* idx, const float* queries, bool from_hos
         idx->stats.path = st.path; idx->stats.kprime = st.kprime;
         idx->stats.scan_launches += st.scan_launches;
         idx->stats.fallback_queries += st.fallback_queries;
+        idx->stats.split_pass |= st.split_pass;
         idx->stats.scan_ms = std::max(idx->stats.scan_ms, st.scan_ms);
         idx->stats.total_ms = std::max(idx->stats.total_ms, st.total_ms);
         idx->stats.scan_bytes += st.scan_bytes; idx->stats.scan_flops += st.scan_flops;
@@ -1026,7 +1051,11 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
     // rows are padded to whole 128-B lines: 64 bf16 / 32 fp32 elements
     idx->ld = (uint32_t)round_up(dim, dtype == VROD_DTYPE_BF16 ? 64 : 32);
     idx->ldp = (uint32_t)round_up(dim, 64);
-    { const char* e = getenv("VROD_F32_SPLIT"); idx->split_enabled = dtype == VROD_DTYPE_F32 && e && e[0] == '1'; }
+    {
+        const char* e = getenv("VROD_F32_SPLIT");
+        idx->split_enabled = dtype == VROD_DTYPE_F32 && !(e && e[0] == '0');
+        idx->split_forced = idx->split_enabled && e && e[0] == '1';
+    }
     int rc = VROD_OK;
     do {
         if (hipSetDevice(dev) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipSetDevice failed"); break; }
