@@ -14,7 +14,11 @@ for trial in range(6):
     dim = int(rng.choice([32, 100, 192]))
     dtype = ["f32", "bf16"][int(rng.integers(2))]
     metric = ["cosine", "l2"][int(rng.integers(2))]
-    os.environ["VROD_F32_SPLIT"] = str(int(rng.integers(2)))
+    mode = int(rng.integers(3))            # fp32 batches: fp32 MFMA pass / forced split pass / the library's default
+    if mode == 2:
+        os.environ.pop("VROD_F32_SPLIT", None)
+    else:
+        os.environ["VROD_F32_SPLIT"] = str(mode)
     DT = 0 if dtype == "f32" else 1
     ME = 0 if metric == "cosine" else 1
     rows = np.zeros((0, dim), np.float32)
