@@ -300,6 +300,38 @@ def test_max_k(va, oracle, path):
 
 
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
+@pytest.mark.parametrize("dim,nq", [(40, 5), (129, 16), (300, 17), (768, 33), (768, 64), (1100, 64), (1536, 32), (1536, 40), (2300, 9)])
+def test_bf16_skinny_kernel_batches_up_to_64(va, oracle, dim, nq, metric):
+    """5..64 queries over bf16 rows: the skinny MFMA kernel (rows streamed from HBM into A fragments,
+    queries resident in LDS; 32- or 64-query form by what fits in LDS -- (1536, 40) and (2300, 9) do
+    not fit and take the tiled kernel).  Odd line counts per row, staged plan (N > list capacity: dense
+    sample + filtered stages), a last 64-row block that is partly padding, unnormalised rows for L2."""
+    rng = np.random.default_rng(dim * 100 + nq)
+    n, k = 20333, 10
+    raw = (rng.standard_normal((n, dim)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    rq = rng.standard_normal((nq, dim)).astype(np.float32)
+    st = run_case(va, oracle, raw, rq, k, "bf16", metric, 2)
+    assert st["path"] == 2 and st["scan_launches"] >= 2
+    st = run_case(va, oracle, raw[:700], rq, 50, "bf16", metric, 2)      # everything appended, one launch
+    assert st["path"] == 2
+
+
+def test_bf16_skinny_kernel_heavy_appends_and_ties(va, oracle):
+    """Thousands of identical rows beat every threshold at once: the wave-private log segments
+    overflow into direct appends, the lists overflow their capacity, and the certificate must
+    send those queries to the exact path."""
+    rng = np.random.default_rng(91)
+    base = rng.standard_normal((3000, 128)).astype(np.float32)
+    dup = np.repeat(rng.standard_normal((1, 128)).astype(np.float32), 9000, axis=0)
+    raw = np.concatenate([base, dup, base[:2000] * 1.5])
+    rq = rng.standard_normal((40, 128)).astype(np.float32)
+    rq[::3] = dup[0] + 0.05 * rng.standard_normal((14, 128)).astype(np.float32)
+    for metric in ("cosine", "l2"):
+        st = run_case(va, oracle, raw, rq, 20, "bf16", metric, 2)
+        assert st["fallback_queries"] >= 14
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
 @pytest.mark.parametrize("dim", [40, 129, 300, 768])   # bf16 K-tiles per row: 1, 3 (odd), 5, 12
 def test_bf16_4wave_kernel_ktile_counts(va, oracle, dim, metric):
     """The 4-wave MFMA kernel alternates two register roles per K-tile and peels the first K-tile

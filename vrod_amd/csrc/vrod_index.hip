@@ -580,7 +580,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         const void* qmat = idx->dtype == VROD_DTYPE_BF16 ? q_lp : P.q_f32.p;
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
-        a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.metric = idx->metric;
+        a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.nq = nq; a.metric = idx->metric;
         int scan_dtype = idx->dtype;
         if (split) {
             // planes of the rows added since the last batched search, and of this batch's queries

@@ -147,6 +147,7 @@ struct MfmaScanArgs {
     uint32_t lda_bytes;     // split-bf16 pass over fp32 rows (bf16 4-wave kernel, a_wrap != 0): the corpus row
     uint32_t a_wrap;        // stride in bytes ([hi_j | lo_j] planes; the query rows are [hi_j | lo_j | hi_j])
     uint32_t nq_pad;
+    uint32_t nq;            // real queries (<= nq_pad): batches of <= 64 over bf16 rows take the skinny kernel
     uint32_t row_begin;     // appends are limited to rows [row_begin, row_end); the launch
     uint32_t row_end;       // starts at the 256-row tile containing row_begin
     int metric;
