@@ -36,7 +36,7 @@ def run_case(va, O, raw, rq, k, dtype, metric, path, id_offset=0):
     oi, osc = O.search(raw, rq, k, DT[dtype], ME[metric], id_offset=id_offset)
     # a batched search over an fp32 corpus has two fast passes (the fp32 MFMA kernel, and by default
     # the bf16 split pass over [hi | lo] planes): both must give the oracle's bits
-    modes = ("0", None) if dtype == "f32" and path in (0, 2) and rq.shape[0] > 12 else (None,)
+    modes = ("0", None) if dtype == "f32" and path in (0, 2) and rq.shape[0] > 4 else (None,)
     for mode in modes:
         with f32_split(mode), va.Index(raw.shape[1], dtype, metric) as ix:
             ix.add(raw)

@@ -37,7 +37,10 @@ def bits(a):
 
 
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
-@pytest.mark.parametrize("dim,nq,k", [(100, 40, 10), (129, 300, 100), (768, 64, 10), (64, 13, 1000)])
+# (batches of <= 32 queries take the skinny form of the split pass where [hi | lo] of the queries fit
+#  in LDS: 16 queries at d = 1536, 32 at d = 768)
+@pytest.mark.parametrize("dim,nq,k", [(100, 40, 10), (129, 300, 100), (768, 64, 10), (64, 13, 1000),
+                                      (768, 13, 10), (768, 30, 10), (300, 17, 50), (1536, 16, 10), (1536, 20, 10)])
 def test_split_pass_is_bit_exact(va, oracle, split_env, metric, dim, nq, k):
     rng = np.random.default_rng(dim + nq)
     n = 30011
@@ -69,9 +72,13 @@ def test_split_is_the_default_but_not_for_small_batches_or_when_switched_off(va,
     oi, osc = oracle.search(raw, rq, 10, 0, 0)
     with f32_split(None), va.Index(96, "f32", "cosine") as ix:
         ix.add(raw)
-        ix.search(rq8, 10)
-        assert ix.last_stats()["path"] == 1          # 8 queries: the stream scan, split or not
+        ix.search(rq8[:4], 10)
+        assert ix.last_stats()["path"] == 1          # 4 queries: the stream scan, split or not
         assert ix.last_stats()["split_pass"] == 0
+        i8, s8 = ix.search(rq8, 10)                  # 5-32 queries: the skinny form of the split pass
+        assert ix.last_stats()["path"] == 2 and ix.last_stats()["split_pass"] == 1
+        o8, os8 = oracle.search(raw, rq8, 10, 0, 0)
+        assert np.array_equal(i8, o8) and np.array_equal(bits(s8), bits(os8))
         ids, sc = ix.search(rq, 10)
         st = ix.last_stats()
         assert st["path"] == 2 and st["split_pass"] == 1 and st["kprime"] == 10 + 32

@@ -1062,18 +1062,24 @@ constexpr int kSkMT = VROD_SK_MT;      // 16-row A fragments per block
 
 template <int NT> constexpr uint32_t skinny_lds_bytes(uint32_t ld_bytes) { return (uint32_t)NT * 16u * (ld_bytes + 16u) + (uint32_t)kSkWaves * kSkLog * 8u; }
 
-template <int METRIC, bool DENSE, int NT>
+template <int METRIC, bool DENSE, int NT, bool SPLIT>
 __global__ __launch_bounds__(kSkWaves * 64) void scan_mfma_skinny_kernel(const MfmaKernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t fr = lane & 15, fg = lane >> 4;
-    const uint32_t qstride = a.ld_bytes + 16;      // +16 B: the 16 query rows of a fragment read fall into different banks
+    // SPLIT (bf16 planes of fp32 rows, kernels_prep.hip split_rows_kernel): a corpus row is
+    // [hi_j | lo_j] per 64-element K-tile (row_bytes = lda_bytes), a query row [hi_j | lo_j | hi_j]
+    // (ld_bytes); LDS keeps [hi_j | lo_j] of every query.  Line 2j of a row (hi_x) meets hi_q and
+    // lo_q of K-tile j, line 2j+1 (lo_x) meets hi_q: q.x ~ hi.hi + hi.lo + lo.hi.
+    const uint32_t row_bytes = SPLIT ? a.lda_bytes : a.ld_bytes;
+    const uint32_t qstride = row_bytes + 16;       // +16 B: the 16 query rows of a fragment read fall into different banks
     constexpr uint32_t NQ = NT * 16;
     {
-        const uint32_t cpr = a.ld_bytes >> 4;      // 16-B chunks per query row
+        const uint32_t cpr = row_bytes >> 4;       // 16-B chunks per query row in LDS
         for (uint32_t c = tid; c < NQ * cpr; c += kSkWaves * 64) {
             const uint32_t r = c / cpr, o = c - r * cpr;
-            *reinterpret_cast<uint4*>(lds + r * qstride + o * 16) = *reinterpret_cast<const uint4*>(a.queries + (uint64_t)r * a.ld_bytes + o * 16);
+            const uint32_t so = SPLIT ? ((o >> 4) * 384u + ((o >> 3) & 1u) * 128u + (o & 7u) * 16u) : o * 16u;
+            *reinterpret_cast<uint4*>(lds + r * qstride + o * 16) = *reinterpret_cast<const uint4*>(a.queries + (uint64_t)r * a.ld_bytes + so);
         }
     }
     __syncthreads();
@@ -1084,7 +1090,7 @@ __global__ __launch_bounds__(kSkWaves * 64) void scan_mfma_skinny_kernel(const M
         thr[n] = a.thr[n * 16 + fr];
         qn2[n] = METRIC == M_L2 ? a.qnorm2[n * 16 + fr] : 0.0f;
     }
-    const uint32_t KP = a.ld_bytes >> 7;           // 128-B lines per row
+    const uint32_t KP = row_bytes >> 7;            // 128-B lines per row
     const uint32_t rel_base = a.tile_first * kBM;
     constexpr int MT = kSkMT;
     const uint32_t nblk = a.ntiles * (kBM / (16 * MT));
@@ -1099,6 +1105,7 @@ __global__ __launch_bounds__(kSkWaves * 64) void scan_mfma_skinny_kernel(const M
     if (!nmine) return;
     const uint32_t total = nmine * KP;
     constexpr int D = VROD_SK_D;
+    static_assert(!SPLIT || (D % 2 == 0 && VROD_SK_G % 2 == 0), "SPLIT pairs ring-slot parity with plane parity");
     bf16x8 ring[D][MT][2];
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -1107,18 +1114,18 @@ __global__ __launch_bounds__(kSkWaves * 64) void scan_mfma_skinny_kernel(const M
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     // fetch cursor (runs D lines ahead of the compute cursor)
     uint32_t f_kp = 0, f_blk = b0, f_it = 0;
-    const char* f_src = a.corpus + (uint64_t)(rel_base + b0 * (16 * MT) + fr) * a.ld_bytes + fg * 16;
+    const char* f_src = a.corpus + (uint64_t)(rel_base + b0 * (16 * MT) + fr) * row_bytes + fg * 16;
     auto fetch1 = [&](bf16x8 (&rs)[2], int m) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            rs[h] = VROD_SK_LOAD(reinterpret_cast<const bf16x8*>(f_src + (uint64_t)m * 16 * a.ld_bytes + f_kp * 128 + h * 64));
+            rs[h] = VROD_SK_LOAD(reinterpret_cast<const bf16x8*>(f_src + (uint64_t)m * 16 * row_bytes + f_kp * 128 + h * 64));
     };
     auto fetch_advance = [&]() {
         ++f_it;
         if (++f_kp == KP) {
             f_kp = 0;
             f_blk += bstep;
-            f_src = a.corpus + (uint64_t)(rel_base + f_blk * (16 * MT) + fr) * a.ld_bytes + fg * 16;
+            f_src = a.corpus + (uint64_t)(rel_base + f_blk * (16 * MT) + fr) * row_bytes + fg * 16;
         }
     };
 #pragma unroll
@@ -1132,11 +1139,13 @@ __global__ __launch_bounds__(kSkWaves * 64) void scan_mfma_skinny_kernel(const M
     auto line = [&](auto dc, uint32_t it) __attribute__((always_inline)) -> bool {
         constexpr int d = decltype(dc)::value;
         if (it >= total) return false;
+        // (SPLIT: KP and D are even and a block starts at a multiple of KP, so the slot's parity is the line's)
+        constexpr bool lo_x = SPLIT && (d & 1);
         bf16x8 bq[2][NT];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bq[h][n] = *reinterpret_cast<const bf16x8*>(qfrag + n * 16 * qstride + c_kp * 128 + h * 64);
+            for (int n = 0; n < NT; ++n) bq[h][n] = *reinterpret_cast<const bf16x8*>(qfrag + n * 16 * qstride + (c_kp - (lo_x ? 1u : 0u)) * 128 + h * 64);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1144,6 +1153,19 @@ __global__ __launch_bounds__(kSkWaves * 64) void scan_mfma_skinny_kernel(const M
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[d][m][h], bq[h][n], acc[m][n], 0, 0, 0);
+        if constexpr (SPLIT && !(d & 1)) {   // hi_x . lo_q
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bq[h][n] = *reinterpret_cast<const bf16x8*>(qfrag + n * 16 * qstride + (c_kp + 1) * 128 + h * 64);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[d][m][h], bq[h][n], acc[m][n], 0, 0, 0);
+        }
         // refill in bursts of G lines (G x 128 contiguous bytes of every row requested together:
         // DRAM page locality), as soon as the last line of a group of ring slots is consumed
         constexpr int G = VROD_SK_G;
@@ -1267,6 +1289,16 @@ __global__ __launch_bounds__(kSkWaves * 64) void scan_mfma_skinny_kernel(const M
     }
 }
 
+// Largest batch the skinny kernel takes for rows of `row_bytes` (bf16 rows, or the [hi | lo] planes
+// of the split pass): what fits in LDS beside the wave logs.  0: none (VROD_MFMA_SKINNY=0, long rows).
+uint32_t mfma_skinny_max_queries(bool split, uint32_t row_bytes) {
+    static const bool skinny_on = [] { const char* e = getenv("VROD_MFMA_SKINNY"); return !e || e[0] != '0'; }();
+    if (!skinny_on) return 0;
+    const uint32_t lds_cap = 160u * 1024u;
+    if (!split) return skinny_lds_bytes<4>(row_bytes) <= lds_cap ? 64u : skinny_lds_bytes<2>(row_bytes) <= lds_cap ? 32u : 0u;
+    return skinny_lds_bytes<2>(row_bytes) <= lds_cap ? 32u : skinny_lds_bytes<1>(row_bytes) <= lds_cap ? 16u : 0u;
+}
+
 void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t s) {
     const LaunchEvents lev = g_launch_events;   // attached to the dispatch (first / last of a split batch)
     g_launch_events = LaunchEvents{};
@@ -1327,26 +1359,34 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     } while (0)
 #define VROD_MFMA_W4K(MM, DN) do { if (split) VROD_MFMA_W4K_(MM, DN, true); else VROD_MFMA_W4K_(MM, DN, false); } while (0)
     const bool split = h.a_wrap != 0;
-    static const bool skinny_on = [] { const char* e = getenv("VROD_MFMA_SKINNY"); return !e || e[0] != '0'; }();
-    if (dtype == DT_BF16 && !split && skinny_on && h.nq > 0 && h.nq <= 64) {
-        const int nt = (h.nq > 32 && skinny_lds_bytes<4>(a.ld_bytes) <= 160u * 1024u) ? 4
-                     : (h.nq <= 32 && skinny_lds_bytes<2>(a.ld_bytes) <= 160u * 1024u) ? 2 : 0;
+    if (dtype == DT_BF16 && h.nq > 0 && h.nq <= mfma_skinny_max_queries(split, split ? a.lda_bytes : a.ld_bytes)) {
+        // rows in LDS: the K extent of a corpus row ([hi | lo] planes in the split form)
+        const uint32_t qrow = split ? a.lda_bytes : a.ld_bytes;
+        const uint32_t lds_cap = 160u * 1024u;
+        int nt = 0;
+        if (!split) nt = (h.nq > 32) ? 4 : 2;
+        else nt = (h.nq > 16 || skinny_lds_bytes<1>(qrow) > lds_cap) ? 2 : 1;
+        if (!split && nt == 2 && skinny_lds_bytes<2>(qrow) > lds_cap) nt = 0;   // (cannot happen: max_queries said so)
         if (nt) {
-            // one wave per 64-row block at a time; all CUs, but no more work-groups than blocks / 8
+            // one wave per 16-row block at a time; all CUs, but no more work-groups than blocks / 8
             const uint32_t nblk = a.ntiles * (kBM / (16 * kSkMT));
             const int sgrid = (int)std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)num_cus, (nblk + kSkWaves - 1) / kSkWaves));
-            const uint32_t lds_bytes = nt == 4 ? skinny_lds_bytes<4>(a.ld_bytes) : skinny_lds_bytes<2>(a.ld_bytes);
-#define VROD_MFMA_SK(MM, DN, NN)                                                                            \
+            const uint32_t lds_bytes = nt == 4 ? skinny_lds_bytes<4>(qrow) : nt == 2 ? skinny_lds_bytes<2>(qrow) : skinny_lds_bytes<1>(qrow);
+#define VROD_MFMA_SK(MM, DN, NN, SP)                                                                        \
     do {                                                                                                    \
         static bool attr_set = false;                                                                       \
         if (!attr_set) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)scan_mfma_skinny_kernel<MM, DN, NN>,                     \
+            (void)hipFuncSetAttribute((const void*)scan_mfma_skinny_kernel<MM, DN, NN, SP>,                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        hipExtLaunchKernelGGL((scan_mfma_skinny_kernel<MM, DN, NN>), dim3(sgrid), dim3(kSkWaves * 64), lds_bytes, s, lev.start, lev.stop, 0, a); \
+        hipExtLaunchKernelGGL((scan_mfma_skinny_kernel<MM, DN, NN, SP>), dim3(sgrid), dim3(kSkWaves * 64), lds_bytes, s, lev.start, lev.stop, 0, a); \
     } while (0)
-#define VROD_MFMA_SKN(MM, DN) do { if (nt == 4) VROD_MFMA_SK(MM, DN, 4); else VROD_MFMA_SK(MM, DN, 2); } while (0)
+#define VROD_MFMA_SKN(MM, DN)                                                                               \
+    do {                                                                                                    \
+        if (split) { if (nt == 2) VROD_MFMA_SK(MM, DN, 2, true); else VROD_MFMA_SK(MM, DN, 1, true); }      \
+        else { if (nt == 4) VROD_MFMA_SK(MM, DN, 4, false); else VROD_MFMA_SK(MM, DN, 2, false); }          \
+    } while (0)
             if (h.metric == M_COSINE) { if (h.dense_out) VROD_MFMA_SKN(M_COSINE, true); else VROD_MFMA_SKN(M_COSINE, false); }
             else { if (h.dense_out) VROD_MFMA_SKN(M_L2, true); else VROD_MFMA_SKN(M_L2, false); }
 #undef VROD_MFMA_SKN

@@ -403,8 +403,11 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     // than the stream scan from ~12 queries on)
     const bool can_split = idx->split_enabled && idx->dtype == VROD_DTYPE_F32 && N > 0 &&
                            (uint64_t)k + std::max<uint32_t>(32, k / 2) <= kSelectChunk / 2;
+    // (5-32 queries over the planes take the skinny form where the queries' [hi | lo] fit in LDS: one HBM pass
+    // over the planes, 1.30 ms at 2M x 768 against 1.34-1.36 for a stream pass of 5-8 queries and 1.85 tiled)
+    const bool skinny_split = can_split && nq <= mfma_skinny_max_queries(true, 2u * idx->ldp * 2u);
     if (path == VROD_PATH_AUTO)
-        path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 4u : can_split ? 12u : 32u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
+        path = nq <= (idx->dtype == VROD_DTYPE_BF16 ? 4u : skinny_split ? 4u : can_split ? 12u : 32u) ? VROD_PATH_STREAM : VROD_PATH_MFMA;
     bool split = can_split && path == VROD_PATH_MFMA;
     if (split && idx->planes_cap < idx->capacity) {
         // the planes are a second copy of the corpus: without room for them the handle quietly

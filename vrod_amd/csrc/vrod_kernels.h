@@ -157,5 +157,8 @@ struct MfmaScanArgs {
     uint32_t dense_ld;      // (column = row - row_begin; multiple of 256)
 };
 void launch_scan_mfma(const MfmaScanArgs& a, int dtype, int num_cus, hipStream_t s);
+// Largest batch the skinny (HBM-bound, <= 64 queries) form of the MFMA scan takes for bf16 rows of
+// `row_bytes` bytes (split == true: the [hi | lo] planes of an fp32 corpus); 0 = none.
+uint32_t mfma_skinny_max_queries(bool split, uint32_t row_bytes);
 
 }  // namespace vrod
