@@ -331,13 +331,29 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const float* __restr
     const float* sc = scores + (uint64_t)blockIdx.x * score_ld;
     const uint32_t tid = threadIdx.x;
     if (j <= 256) {
+        // (rows of the dense block start 16-B aligned and are padded to 256 floats: 16-B loads,
+        //  8 of them in flight per thread; elements at or beyond n are masked, not trusted)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 none4 = {__uint_as_float(kScoreNoneBits), __uint_as_float(kScoreNoneBits), __uint_as_float(kScoreNoneBits), __uint_as_float(kScoreNoneBits)};
+        const uint32_t n4 = (n + 3) / 4;
+        auto load4 = [&](uint32_t i4) -> f4 {
+            if (i4 >= n4) return none4;
+            f4 v = *reinterpret_cast<const f4*>(sc + (uint64_t)i4 * 4);
+            if (i4 * 4 + 3 >= n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (i4 * 4 + e >= n) v[e] = __uint_as_float(kScoreNoneBits);
+            }
+            return v;
+        };
         uint32_t best = 0;
-        for (uint32_t i0 = 0; i0 < n; i0 += 256 * 8) {   // 8 independent loads in flight per thread
-            float v[8];
+        for (uint32_t i0 = 0; i0 < n4; i0 += 256 * 8) {
+            f4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 256 + tid; v[u] = i < n ? sc[i] : __uint_as_float(kScoreNoneBits); }
+            for (int u = 0; u < 8; ++u) v[u] = load4(i0 + u * 256 + tid);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint32_t k = score_key<METRIC>(v[u]); best = k > best ? k : best; }
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const uint32_t k = score_key<METRIC>(v[u][e]); best = k > best ? k : best; }
         }
         hist[tid] = best;
         if (tid == 0) ctl[6] = 0u;
@@ -349,15 +365,17 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const float* __restr
         __syncthreads();
         const uint32_t L = ctl[7];
         uint32_t* list = hist + 1024;   // [kSampleListCap]
-        for (uint32_t i0 = 0; i0 < n; i0 += 256 * 8) {
-            float v[8];
+        for (uint32_t i0 = 0; i0 < n4; i0 += 256 * 8) {
+            f4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 256 + tid; v[u] = i < n ? sc[i] : __uint_as_float(kScoreNoneBits); }
+            for (int u = 0; u < 8; ++u) v[u] = load4(i0 + u * 256 + tid);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t k = score_key<METRIC>(v[u]);   // NaN padding -> key 0 < L
-                if (k >= L && k != 0u) { const uint32_t p = atomicAdd(&ctl[6], 1u); if (p < kSampleListCap) list[p] = k; }
-            }
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t k = score_key<METRIC>(v[u][e]);   // NaN padding -> key 0 < L
+                    if (k >= L && k != 0u) { const uint32_t p = atomicAdd(&ctl[6], 1u); if (p < kSampleListCap) list[p] = k; }
+                }
         }
         __syncthreads();
         const uint32_t m = ctl[6];
