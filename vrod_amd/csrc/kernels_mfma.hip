@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #define VROD_SK_G 4      // lines requested together
 #endif
 #ifndef VROD_SK_LOAD
-#define VROD_SK_LOAD(p) (*(p))
+#define VROD_SK_LOAD(p) __builtin_nontemporal_load(p)   // (with the continuous ring: same at 32 queries, 2-4 % faster at 64 than plain loads)
 #endif
 constexpr int kSkLog = 256;   // log entries per wave
 #ifndef VROD_SK_WAVES
