@@ -1,9 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- the driver's measurement contract for the vRod similarity-scan hot path.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 without a launcher this
+        process starts the N ranks itself -- before importing torch or touching a GPU -- relays
+        rank 0's JSON line and exits with the ranks' return code)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --inprocess                   (ONE process, one multi-device handle:
+        vrod_index_create(n_devices = N), the exchange is the library's own RCCL all-gather)
 
 One "step" = one batch of queries through the whole search (fast scan -> candidates ->
 canonical re-score -> certified top-k), corpus resident in HBM before the timed region.
@@ -58,7 +62,33 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override total corpus rows (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true", help="skip the extra 1-query HBM-roofline probe (cfg2)")
+    ap.add_argument("--no-host-probe", action="store_true", help="skip the host-pointer (vrod_search, PCIe-inclusive) probe")
+    ap.add_argument("--inprocess", action="store_true",
+                    help="one process, one handle over --gpus devices (vrod_index_create n_devices > 1, RCCL inside the library)")
     return ap.parse_args()
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` (N > 1) with no launcher: start the N ranks as CHILD processes
+    (`python -m torch.distributed.run ...`), relay rank 0's one JSON line, exit with their code.
+    This parent never imports torch and never touches a GPU (and never re-execs itself)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    lines = [l for l in p.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(f"bench: {args.gpus} ranks ended with code {p.returncode} and {len(lines)} JSON line(s)\n")
+        sys.stderr.write(p.stdout.decode("utf-8", "replace")[-4000:])
+        raise SystemExit(p.returncode or 1)
+    print(lines[0], flush=True)
+    raise SystemExit(0)
 
 
 def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, collective=None):
@@ -81,7 +111,9 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         gathered = torch.empty(world * bufs[0][0].numel(), dtype=torch.uint8, device=dev)
         mi = torch.empty((nq, k), dtype=torch.int64, device=dev)
         ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, max_err=0.0, eps=0.0, split=0)
+    acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, max_err=0.0, eps=0.0, split=0,
+               exchange_ms=0.0, exchange_host_ms=0.0)
+    ex_events = []   # (start, stop) on torch's stream around all-gather + merge of every batch
 
     def begin(s):
         _, oi, osc = bufs[s % depth]
@@ -97,8 +129,14 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         packed, oi, osc = bufs[s % depth]
         if collective:
             # per-shard top-k -> every rank (RCCL all-gather over xGMI), then the exact merge
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            h0 = time.perf_counter()
+            e0.record()
             all_gather_packed(dist, packed, gathered)
             va.merge_topk_packed_device(dev.index, wl["metric"], gathered, world, nq, k, mi, ms)
+            e1.record()
+            acc["exchange_host_ms"] += (time.perf_counter() - h0) * 1e3
+            ex_events.append((e0, e1))
         if depth == 1 and s + 1 < steps:
             begin(s + 1)
         acc["scan_ms"] += st["scan_ms"]
@@ -109,6 +147,9 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         acc["split"] += st["split_pass"]
         acc["max_err"] = max(acc["max_err"], st["max_fast_err"])
         acc["eps"] = st["eps_bound"]
+    if ex_events:
+        torch.cuda.synchronize(dev)
+        acc["exchange_ms"] = sum(a.elapsed_time(b) for a, b in ex_events)
     final = (mi, ms) if collective else (bufs[(steps - 1) % depth][1], bufs[(steps - 1) % depth][2])
     return acc, final
 
@@ -145,6 +186,9 @@ def cpu_baseline(wl, va, torch, dev, n_total):
     t = time.time()
     raw = O.synth_rows(CORPUS_SEED, 0, ns, dim, threads=cores)
     corpus = O.prepare(raw, DT[wl["dtype"]], ME[wl["metric"]], threads=cores)
+    # bf16 workloads: also the oracle over the ORIGINAL fp32 data ("additionally
+    # reported against the fp32-data oracle, labelled separately"), on a smaller query sample
+    corpus32 = O.prepare(raw, DT["f32"], ME[wl["metric"]], threads=cores) if wl["dtype"] == "bf16" else None
     del raw
     # size the query samples for ~12 s (all cores) and ~6 s (one thread) at ~2.5e9 mul-add/s/thread
     q_all = int(max(2, min(512, 12.0 * 2.5e9 * cores / (ns * dim))))
@@ -176,11 +220,122 @@ def cpu_baseline(wl, va, torch, dev, n_total):
     hits = sum(len(set(ids[i].tolist()) & set(oi[i].tolist())) for i in range(q_all))
     recall = hits / float(q_all * min(k, ns))
     bit_exact = bool(np.array_equal(ids, oi) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32)))
-    return out, recall, bit_exact, f"{q_all} queries vs oracle on the first {ns} rows"
+    extra = {}
+    if corpus32 is not None:
+        q32 = min(q_all, 64)
+        pq32 = O.prepare(rq[:q32], DT["f32"], ME[wl["metric"]])
+        fi, fs = O.scan_topk(corpus32, pq32, k, ME[wl["metric"]], threads=cores)
+        hits32 = sum(len(set(ids[i].tolist()) & set(fi[i].tolist())) for i in range(q32))
+        rel = np.abs(sc[:q32].astype(np.float64) - fs.astype(np.float64)) / np.maximum(np.abs(fs.astype(np.float64)), 1e-30)
+        same = ids[:q32] == fi
+        extra[f"recall_at_{k}_vs_fp32_oracle"] = round(hits32 / float(q32 * min(k, ns)), 6)
+        extra["fp32_oracle_note"] = (f"{q32} queries, first {ns} rows: the HIP bf16 result against the oracle over the UN-rounded fp32 data "
+                                     "(bf16 storage moves neighbours near the k-th boundary; the bf16-data oracle above is the parity target); "
+                                     f"max relative score difference where the ids agree: {float(rel[same].max()) if same.any() else 0.0:.3e}")
+    return out, recall, bit_exact, f"{q_all} queries vs oracle on the first {ns} rows", extra
+
+
+def main_inprocess(args):
+    """ONE process, ONE handle over N devices (vrod_index_create with n_devices = N): the deployment a
+    single-threaded host like vRod uses.  Rows are dealt to the devices in blocks of 65536; each batch
+    is scanned on every device, the per-shard top-k travel through the library's own RCCL all-gather
+    (ncclCommInitAll communicator, one ncclAllGather per device in a group call) and are merged on the
+    first device.  Two batches in flight, as in the multi-process form.
+    VROD_BENCH_DEVICES=0,0: the device list (rehearsal on fewer GPUs than shards)."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import vrod_amd as va
+    va.load()
+    devs = [int(x) for x in os.environ.get("VROD_BENCH_DEVICES", ",".join(str(i) for i in range(args.gpus))).split(",")]
+    if len(devs) != args.gpus:
+        raise SystemExit(f"bench: VROD_BENCH_DEVICES names {len(devs)} devices but --gpus {args.gpus}")
+    wl = dict(WORKLOADS[args.workload])
+    n_total = args.rows or wl["n"]
+    nq, k = wl["nq"], wl["k"]
+    dev = torch.device("cuda", devs[0])
+    torch.cuda.set_device(dev)
+    ix = va.Index(wl["dim"], wl["dtype"], wl["metric"], devices=devs) if len(devs) > 1 else va.Index(wl["dim"], wl["dtype"], wl["metric"], device=devs[0])
+    ix.add_synthetic(CORPUS_SEED, 0, n_total)
+    ix.set_profiling(True)
+    outs = [(torch.empty((nq, k), dtype=torch.int64, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev)) for _ in range(2)]
+
+    def run(steps, first):
+        acc = dict(scan_ms=0.0, scan_flops=0.0, launches=0, fallback=0, exchange=0, split=0)
+        if steps:
+            ix.search_begin_synthetic_device(QUERY_SEED, first * nq, nq, k, *outs[0])
+        for s in range(steps):
+            if s + 1 < steps:
+                ix.search_begin_synthetic_device(QUERY_SEED, (first + s + 1) * nq, nq, k, *outs[(s + 1) % 2])
+            ix.search_end()
+            st = ix.last_stats()
+            acc["scan_ms"] += st["scan_ms"]          # slowest device of the batch
+            acc["scan_flops"] += st["scan_flops"]    # all devices
+            acc["launches"] += st["scan_launches"]
+            acc["fallback"] += st["fallback_queries"]
+            acc["exchange"] = st["exchange"]
+            acc["split"] += st["split_pass"]
+        return acc
+
+    def sync_all():
+        for d in sorted(set(devs)):
+            torch.cuda.synchronize(d)
+
+    run(args.warmup, 0)
+    sync_all()
+    t0 = time.perf_counter()
+    acc = run(args.steps, args.warmup)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    G = len(devs)
+    factor = 3.0 if acc["split"] else 1.0
+    per_gpu = factor * acc["scan_flops"] / G / (acc["scan_ms"] * 1e-3) / 1e12 if acc["scan_ms"] else 0.0
+    peak, unit = PEAK["mfma_bf16" if wl["dtype"] == "bf16" or acc["split"] else "mfma_f32"]
+    if wl["bound"] == "hbm":
+        peak, unit = PEAK["hbm"]
+        per_gpu = 0.0
+    out = {
+        "metric": baseline_metric() if args.workload == "cfg3" and not args.rows else f"queries/sec, {args.workload}",
+        "value": round(nq * args.steps / elapsed, 2), "unit": "queries/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": wl["dtype"], "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n_total} x {wl['dim']} {wl['dtype']} {wl['metric']}, batch={nq}, top-{k}", "rows_total": n_total,
+                   "dim": wl["dim"], "batch": nq, "k": k, "metric": wl["metric"], "devices": devs,
+                   "parallelism": f"ONE process, one handle over {G} devices (rows dealt in blocks of 65536); exchange = "
+                                  + {0: "none", 1: "RCCL all-gather inside the library (ncclCommInitAll)", 2: "peer copies (VROD_RCCL=0)"}[acc["exchange"]],
+                   "corpus_seed": CORPUS_SEED, "query_seed": QUERY_SEED, "batches_in_flight": 2},
+        "roofline": {"bound": "hbm" if wl["bound"] == "hbm" else "mfma", "achieved": round(per_gpu, 2), "peak": peak, "unit": unit,
+                     "frac": round(per_gpu / peak, 4), "traffic": None, "traffic_source": "not measured in this run",
+                     "kernel": "scan_mfma_w4_kernel", "note": "per GPU: all devices' algorithmic flops / N / the slowest device's scan time per batch",
+                     "launches_per_step": acc["launches"] / max(args.steps, 1)},
+        "exactness": {"certificate_fallback_queries": acc["fallback"]},
+    }
+    if os.environ.get("VROD_BENCH_VERIFY") == "1":
+        with va.Index(wl["dim"], wl["dtype"], wl["metric"], device=devs[0]) as fx:
+            fx.add_synthetic(CORPUS_SEED, 0, n_total)
+            vi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            vs = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            last = args.warmup + args.steps - 1
+            fx.search_synthetic_device(QUERY_SEED, last * nq, nq, k, vi, vs)
+            fi, fs = outs[(args.steps - 1) % 2]
+            out["verify_merged_equals_single_device"] = bool(torch.equal(vi, fi) and torch.equal(vs.view(torch.int32), fs.view(torch.int32)))
+    ix.close()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.inprocess:
+        self_launch(args)   # never returns; this process has not imported torch nor touched a GPU
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench: WORLD_SIZE={os.environ['WORLD_SIZE']} but --gpus {args.gpus}: launch exactly one rank per GPU")
+    if args.inprocess:
+        return main_inprocess(args)
     # stdout carries exactly ONE JSON line.  Native libraries write there too (RCCL prints a
     # version banner at communicator creation), so fd 1 points at stderr until the final print.
     sys.stdout.flush()
@@ -192,9 +347,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # VROD_BENCH_BACKEND=gloo: rehearsal of the N>1 control flow on a box with fewer GPUs than
     # ranks (ranks share devices, the exchange is staged through the host) -- never a measurement
@@ -238,6 +390,7 @@ def main():
     acc, final = run_steps(ix, wl, args.steps, args.warmup, world, rank, dist, va, torch, dev, coll)
     fence()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     if world > 1:
         rdev = dev if backend == "nccl" else torch.device("cpu")
         tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -248,8 +401,16 @@ def main():
         kmax = ks.clone(); dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         ksum = ks.clone(); dist.all_reduce(ksum, op=dist.ReduceOp.SUM)
         fallback_total = int(ksum[3].item())
+        # where a scaling loss sits: every rank's own scan time, exchange time (all-gather + merge on
+        # torch's stream, next batch's scan running beside it) and wall time of the timed region
+        mine = torch.tensor([acc["scan_ms"], acc["exchange_ms"], acc["exchange_host_ms"], my_elapsed * 1e3],
+                            dtype=torch.float64, device=rdev)
+        allr = torch.empty(world * 4, dtype=torch.float64, device=rdev)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank_stats = allr.view(world, 4).cpu().tolist()
     else:
         fallback_total = acc["fallback"]
+        per_rank_stats = [[acc["scan_ms"], acc["exchange_ms"], acc["exchange_host_ms"], elapsed * 1e3]]
 
     if rank == 0:
         nq = wl["nq"]
@@ -275,16 +436,21 @@ def main():
             kernel = "scan_mfma_w4_kernel" if split or (wl["dtype"] == "bf16" and os.environ.get("VROD_MFMA_W4", "1") != "0") else "scan_mfma_phased_kernel"
             per_launch = factor * acc["scan_flops"] / max(acc["launches"], 1)
             work_key = "algorithmic_flops_per_launch"
-        traffic = None
+        # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE pass of this same command
+        # (counters cannot be read from inside the run): the committed summary, never a live value
+        traffic, traffic_source = None, "not measured in this run (rocprofv3 --pmc FETCH_SIZE is a separate pass)"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1 and not args.rows:
             try:
-                traffic = json.load(open(tpath)).get(args.workload if world == 1 else "", {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath)).get(args.workload, {})
+                traffic = tj.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = f"profiles/traffic.json ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE x2, own pass')}; NOT this run)"
             except Exception:
                 traffic = None
         roofline = {
             "bound": "hbm" if wl["bound"] == "hbm" else "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": kernel,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
             "launches_per_step": acc["launches"] / max(args.steps, 1),
             "avg_launch_ms": round(acc["scan_ms"] / max(acc["launches"], 1), 4), work_key: per_launch,
             "timing": "HIP events attached to each scan dispatch on the library's stream (hipExtLaunchKernelGGL start/stop), timed steps only",
@@ -303,6 +469,18 @@ def main():
             "exactness": {"certificate_fallback_queries": fallback_total, "max_fast_err": acc["max_err"], "eps_bound": acc["eps"],
                           "note": "ids and score bits equal the CPU oracle by construction (canonical re-score + certificate)"},
         }
+        if coll:
+            steps_n = max(args.steps, 1)
+            col = lambda j: [r[j] / steps_n for r in per_rank_stats]
+            out["per_rank"] = {
+                "rccl_ranks": world if backend == "nccl" else 0, "backend": backend,
+                "scan_ms_per_step": {"min": round(min(col(0)), 4), "max": round(max(col(0)), 4), "all": [round(x, 4) for x in col(0)]},
+                "allgather_merge_ms_per_step": {"min": round(min(col(1)), 4), "max": round(max(col(1)), 4),
+                                                "note": "HIP events on the exchange stream around all-gather + merge; the next batch's scan runs beside it"},
+                "allgather_merge_host_ms_per_step": {"min": round(min(col(2)), 4), "max": round(max(col(2)), 4)},
+                "wall_ms_per_step": {"min": round(min(col(3)), 4), "max": round(max(col(3)), 4)},
+                "roofline_rank": 0,
+            }
         if os.environ.get("VROD_BENCH_VERIFY") == "1":
             # rehearsal check: the merged result of the last timed batch equals a one-device search of all rows
             with va.Index(wl["dim"], wl["dtype"], wl["metric"], device=dev_index) as fx:
@@ -312,11 +490,27 @@ def main():
                 fx.search_synthetic_device(QUERY_SEED, (args.warmup + args.steps - 1) * nq, nq, wl["k"], vi, vs)
                 out["verify_merged_equals_single_device"] = bool(torch.equal(vi, final[0]) and torch.equal(vs.view(torch.int32), final[1].view(torch.int32)))
         if world == 1 and not args.no_cpu_baseline:
-            cb, recall, bit_exact, rs = cpu_baseline(wl, va, torch, dev, n_total)
+            cb, recall, bit_exact, rs, extra = cpu_baseline(wl, va, torch, dev, n_total)
             out["cpu_baseline"] = cb
             out[f"recall_at_{wl['k']}"] = round(recall, 6)
             out["recall_sample"] = rs
             out["bit_exact_vs_oracle_on_sample"] = bit_exact
+            out["parity"] = "unpinned by the reference (vRod holds no scan, tests or vectors): the oracle is a build-authored restatement"
+            out.update(extra)
+        if world == 1 and not args.no_host_probe:
+            # the boundary as SURVEY.md 8(b) specifies it: vrod_search, host pointers in, results in host
+            # memory, synchronous (PCIe both ways inside the call).  Reported beside `value`, never as it.
+            hq = va.synth_rows_device(dev_index, QUERY_SEED, 0, nq, wl["dim"]).cpu().numpy()
+            ix.set_profiling(False)
+            ix.search(hq, wl["k"])
+            hsteps = max(3, min(10, args.steps))
+            th = time.perf_counter()
+            for _ in range(hsteps):
+                ix.search(hq, wl["k"])
+            th = time.perf_counter() - th
+            out["host_pointer_qps"] = {"value": round(nq * hsteps / th, 2), "unit": "queries/s", "ms_per_batch": round(th / hsteps * 1e3, 4),
+                                       "batches": hsteps, "entry_point": "vrod_search (host fp32 queries in, host ids + scores out, synchronous; "
+                                       "one batch at a time, nothing in flight across calls)"}
         if world == 1 and not args.no_hbm_probe and args.workload == "cfg3":
             # the north_star's second roofline: the memory-bound 1-query scan (configs[1])
             ix.close()

@@ -76,17 +76,24 @@ typedef struct {
                                  * |canonical| on the direct-L2 stream path, whose bound is relative) */
     float eps_bound;            /* the certificate's bound on that error */
     uint32_t split_pass;        /* 1: the batched fast pass of an F32 handle ran on its bf16 [hi | lo] planes */
-    uint32_t reserved_;
+    uint32_t exchange;          /* multi-device handle: how the per-shard lists reached the merge --
+                                 * 0 none (single device), 1 RCCL all-gather, 2 peer copies (VROD_RCCL=0) */
 } vrod_search_stats;
 
 /* --- lifecycle ------------------------------------------------------------- */
 /* device_ids/n_devices: the GPUs the corpus is sharded over.  n_devices <= 1: one
- * handle drives one GPU (the deployment bench.py measures is one process and one handle per GPU,
- * see vrod_search_device + vrod_merge_topk_device).  n_devices > 1 (at most 64, an id may repeat):
- * ONE handle owns a shard on every listed device; rows are dealt to the shards in blocks of 65536
- * in insertion order, vrod_search runs on all of them at once and merges on device_ids[0], ids are
- * global insertion indices as for a single device.  Device pointers passed to such a handle live
- * on device_ids[0]; the pipelined _begin_/_end form is per device and returns VROD_ERR_UNSUPPORTED. */
+ * handle drives one GPU (bench.py's default deployment is one process and one handle per GPU, see
+ * vrod_search_device + vrod_merge_topk_device).  n_devices > 1 (at most 64, an id may repeat): ONE
+ * handle owns a shard on every listed device -- the single-process model of SURVEY.md 8e, all a
+ * host like vRod (Rc<RefCell<Database>>, one thread) needs.  Rows are dealt to the shards in blocks
+ * of 65536 in insertion order; a search runs on every shard at once; the per-shard top-k lists are
+ * exchanged with ONE ncclAllGather per device (RCCL, communicator from ncclCommInitAll over the
+ * distinct devices, one exchange stream per device, inside ncclGroupStart/End) and merged on
+ * device_ids[0]; ids are global insertion indices as for a single device.  librccl is loaded when
+ * the first such handle is created (VROD_RCCL_LIB: its path; VROD_RCCL=0: peer copies to the first
+ * device instead of RCCL).  Device pointers passed to such a handle live on device_ids[0].  The
+ * pipelined _begin_/_end form works as for one device: while the exchange and merge of batch s run,
+ * every device already scans batch s+1. */
 int vrod_index_create(vrod_index **out, uint32_t dim, int dtype, int metric,
                       const int *device_ids, int n_devices);
 int vrod_index_destroy(vrod_index *idx);

@@ -1,10 +1,14 @@
 """One handle over several devices (vrod_index_create with n_devices > 1, include/vrod.h).
 
-The rows are dealt to the shards in blocks of 65536; a search runs on every shard at once and is
-merged on the first device.  The 1-GPU test box exercises the whole mechanism by naming device 0
-several times (each entry is a shard with its own corpus, stream and workspaces); results must be
-the bits of the oracle, i.e. of a single-device index.
+The rows are dealt to the shards in blocks of 65536; a search runs on every shard at once, the
+per-shard lists are exchanged with one RCCL all-gather per distinct device and merged on the first
+device.  The 1-GPU test box exercises the whole mechanism by naming device 0 several times (each
+entry is a shard with its own corpus, stream and workspaces; the communicator then has ONE rank and
+that device contributes a block of three lists); results must be the bits of the oracle, i.e. of a
+single-device index.  VROD_RCCL=0 runs the same searches over peer copies.
 """
+import contextlib
+import os
 import numpy as np
 import pytest
 
@@ -27,6 +31,23 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+@contextlib.contextmanager
+def rccl(mode):
+    """VROD_RCCL for the handles created inside (read at vrod_index_create): None = default (RCCL)."""
+    old = os.environ.get("VROD_RCCL")
+    if mode is None:
+        os.environ.pop("VROD_RCCL", None)
+    else:
+        os.environ["VROD_RCCL"] = mode
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("VROD_RCCL", None)
+        else:
+            os.environ["VROD_RCCL"] = old
+
+
 @pytest.mark.parametrize("dtype,metric,path,nq", [("f32", "cosine", 1, 3), ("bf16", "cosine", 2, 40), ("f32", "l2", 0, 1), ("bf16", "l2", 2, 300)])
 def test_three_shards_equal_the_oracle(va, oracle, dtype, metric, path, nq):
     dim, n, k = 32, 3 * 65536 + 70001, 10          # four blocks + a partial one: shard sizes 131072 / 70001+65536 / 65536
@@ -47,6 +68,60 @@ def test_three_shards_equal_the_oracle(va, oracle, dtype, metric, path, nq):
     assert np.array_equal(ids, oi), np.argwhere(ids != oi)[:5]
     assert np.array_equal(bits(sc), bits(osc))
     assert st["nq"] == nq and st["scan_launches"] >= 3
+    assert st["exchange"] == 1                      # the lists travelled through ncclAllGather (1-rank communicator here)
+
+
+@pytest.mark.parametrize("mode,kind", [(None, 1), ("0", 2)])
+@pytest.mark.parametrize("nq,k", [(1, 5), (3, 25), (2, 7)])
+def test_odd_nq_times_k_blocks_stay_aligned(va, oracle, mode, kind, nq, k):
+    """A shard's packed block is nq*k*12 bytes: with nq*k odd the next list used to start 4 bytes off an
+    8-byte stride (ids of every shard but the first were misread).  Blocks are padded to 16 bytes now."""
+    dim, n = 48, 2 * 65536 + 12345
+    raw = oracle.synth_rows(3, 0, n, dim, threads=8)
+    rq = oracle.synth_rows(2, 0, nq, dim)
+    with rccl(mode), va.Index(dim, "f32", "l2", devices=[0, 0, 0]) as ix:
+        ix.add(raw)
+        ids, sc = ix.search(rq, k)
+        st = ix.last_stats()
+    oi, osc = oracle.search(raw, rq, k, 0, 1)
+    assert np.array_equal(ids, oi), (ids, oi)
+    assert np.array_equal(bits(sc), bits(osc))
+    assert st["exchange"] == kind
+
+
+def test_pipelined_searches_on_a_multi_device_handle(va, oracle):
+    """begin(s+1) before end(s) on ONE handle over several shards: the exchange + merge of batch s runs
+    while every shard scans batch s+1; results land in the caller's device buffers in FIFO order."""
+    import torch
+    dim, n, nq, k = 64, 3 * 65536 + 999, 40, 10
+    raw = oracle.synth_rows(1, 0, n, dim, threads=8)
+    with va.Index(dim, "bf16", "cosine", devices=[0, 0]) as ix:
+        ix.add_synthetic(1, 0, n)
+        ix.set_path(va.PATH_MFMA)
+        outs = [(torch.empty((nq, k), dtype=torch.int64, device="cuda"), torch.empty((nq, k), dtype=torch.float32, device="cuda")) for _ in range(2)]
+        got = []
+        steps = 5
+        ix.search_begin_synthetic_device(2, 0, nq, k, *outs[0])
+        for s in range(steps):
+            if s + 1 < steps:
+                if s % 2 == 0:      # alternate the two begin forms
+                    dq = va.synth_rows_device(0, 2, (s + 1) * nq, nq, dim)
+                    ix.search_begin_device(dq, k, *outs[(s + 1) % 2])
+                else:
+                    ix.search_begin_synthetic_device(2, (s + 1) * nq, nq, k, *outs[(s + 1) % 2])
+                assert ix.pending == 2
+                with pytest.raises(va.VrodError):       # a third one must wait
+                    ix.search_begin_synthetic_device(2, 0, nq, k, *outs[0])
+            ix.search_end()
+            got.append((outs[s % 2][0].cpu().numpy().view(np.uint64).copy(), outs[s % 2][1].cpu().numpy().copy()))
+        assert ix.pending == 0
+        with pytest.raises(va.VrodError):
+            ix.search_end()
+    for s in range(steps):
+        rq = oracle.synth_rows(2, s * nq, nq, dim)
+        oi, osc = oracle.search(raw, rq, k, 1, 0, threads=8)
+        assert np.array_equal(got[s][0], oi), s
+        assert np.array_equal(bits(got[s][1]), bits(osc)), s
 
 
 def test_synthetic_add_small_corpus_and_device_pointers(va, oracle):
@@ -62,8 +137,9 @@ def test_synthetic_add_small_corpus_and_device_pointers(va, oracle):
         dq = torch.from_numpy(rq).cuda()
         di, ds = ix.search_device(dq, k)
         assert np.array_equal(di.cpu().numpy().view(np.uint64), oi) and np.array_equal(bits(ds.cpu().numpy()), bits(osc))
-        with pytest.raises(va.VrodError):           # the pipelined form is per device
-            ix.search_begin_device(dq, k, di, ds)
+        ix.search_begin_device(dq, k, di, ds)       # the pipelined form, one batch
+        ix.search_end()
+        assert np.array_equal(di.cpu().numpy().view(np.uint64), oi) and np.array_equal(bits(ds.cpu().numpy()), bits(osc))
     big_k = 1200                                    # k > count: unfilled slots (ID_NONE, NaN) survive the merge
     with va.Index(dim, "f32", "l2", devices=[0, 0]) as ix:
         ix.add(raw)

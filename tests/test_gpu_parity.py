@@ -128,8 +128,9 @@ def test_duplicates_tie_break_by_id(va, oracle, path):
     raw = np.concatenate([base] * 40)  # every row 40 times: massive exact ties
     rq = base[:3] + 0.01 * rng.standard_normal((3, 64)).astype(np.float32)
     st = run_case(va, oracle, raw, rq, 25, "f32", "cosine", path)
-    # ties around the cut defeat the certificate for at least one query -> exact path ran
-    assert st["fallback_queries"] >= 0
+    # every query sits next to a base row that exists 40 times: rank 25 falls inside that group of
+    # exact ties, no certificate can separate s_k from the left-out copies -> the exact path ran
+    assert st["fallback_queries"] >= 1
 
 
 @pytest.mark.parametrize("path", [1, 2])
@@ -181,6 +182,33 @@ def test_rejects_nan_and_bad_args(va):
             ix.search(np.ones((1, 16), np.float32), va.MAX_K + 1)
 
 
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_rejected_add_leaves_the_certificate_bound_alone(va, oracle, dtype, metric):
+    """A rejected add must not leave its rows' norms in the handle's max |x|^2: on an L2 index one
+    Inf row used to void every later certificate (every query of every later search took the exact
+    path, silently), and large finite rejected rows widened the bound the same way."""
+    dim, n, nq = 96, 30000, 24
+    raw = oracle.synth_rows(1, 0, n, dim, threads=4)
+    rq = oracle.synth_rows(2, 0, nq, dim)
+    bad = (raw[:512] * np.float32(3e18)).astype(np.float32)     # huge but finite rows ...
+    bad[100, 5] = np.inf                                        # ... and one Inf: the add is rejected as a whole
+    oi, osc = oracle.search(raw, rq, 10, DT[dtype], ME[metric])
+    for path in (1, 2):
+        with va.Index(dim, dtype, metric) as ix:
+            ix.add(raw[:20000])
+            with pytest.raises(va.VrodError) as e:
+                ix.add(bad)
+            assert e.value.code == 2 and ix.count == 20000
+            ix.add(raw[20000:])
+            ix.set_path(path)
+            ids, sc = ix.search(rq, 10)
+            st = ix.last_stats()
+        assert_same(ids, sc, oi, osc, f"after a rejected add, path {path}")
+        assert st["fallback_queries"] == 0, st
+        assert st["eps_bound"] < 1e-2, st
+
+
 def test_denormal_products_follow_ieee(va, oracle):
     raw = (np.random.default_rng(9).standard_normal((200, 32)) * 1e-22).astype(np.float32)
     rq = (np.random.default_rng(10).standard_normal((2, 32)) * 1e-22).astype(np.float32)
@@ -214,21 +242,27 @@ def test_merge_topk_device_matches_oracle(va, oracle):
 
 
 # ---------------------------------------------------------------- scale / structure cases
-def test_mfma_path_splits_launches_past_2pow24_rows(va, oracle):
-    """Rows are addressed relative to a launch's first tile with 24 bits: a 17M-row shard needs
-    two launches for its last stage (sample 64k rows -> stage to ~1.1M -> 17.9M rows).  64-d bf16
-    keeps it at 2.4 GB; oracle on 8 threads."""
-    n, dim, nq, k = (1 << 24) + 2_300_001, 64, 12, 10
-    with va.Index(dim, "bf16", "cosine") as ix:
+@pytest.mark.parametrize("dtype,metric,nq,split", [("bf16", "cosine", 12, None), ("bf16", "l2", 12, None), ("bf16", "l2", 70, None),
+                                                   ("f32", "cosine", 40, "1"), ("f32", "l2", 70, "1"), ("f32", "l2", 12, "1")])
+def test_mfma_path_splits_launches_past_2pow24_rows(va, oracle, dtype, metric, nq, split):
+    """Rows are addressed relative to a launch's first tile with 24 bits: a 19M-row shard needs
+    two launches for its last stage (sample 64k rows -> stage to ~1.1M -> 19M rows).  64-d rows
+    keep it small (2.4 GB bf16, 4.9 GB fp32 + as much for the [hi | lo] planes); oracle on 8 threads.
+    Covered: the skinny form (12 queries) and the 256-query tile (70), both metrics, and the SPLIT
+    form of both over an fp32 corpus."""
+    from conftest import f32_split
+    n, dim, k = (1 << 24) + 2_300_001, 64, 10
+    with f32_split(split), va.Index(dim, dtype, metric) as ix:
         ix.add_synthetic(1, 0, n)
         ix.set_path(va.PATH_MFMA)
         rq = oracle.synth_rows(2, 0, nq, dim)
         ids, sc = ix.search(rq, k)
         st = ix.last_stats()
     raw = oracle.synth_rows(1, 0, n, dim, threads=8)
-    oi, osc = oracle.search(raw, rq, k, 1, 0, threads=8)
+    oi, osc = oracle.search(raw, rq, k, DT[dtype], ME[metric], threads=8)
     assert_same(ids, sc, oi, osc, "19M rows")
     assert st["fallback_queries"] == 0 and st["scan_launches"] >= 4
+    assert st["split_pass"] == (1 if split == "1" else 0)
 
 
 @pytest.mark.parametrize("dtype,metric", [("bf16", "l2"), ("f32", "l2"), ("bf16", "cosine")])

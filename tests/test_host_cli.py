@@ -112,6 +112,20 @@ def test_bulkinsert_and_searchsimilar_match_oracle(tmp_path, oracle):
     qf.write_text("\n".join(",".join(repr(float(v)) for v in rq[i]) + ";ignored" for i in range(nq)) + "\n")
     r = run("-d", db, "-c", "alice", "-e", "SEARCHSIMILAR", "-a", f"k=3;@{qf}")
     assert r.returncode == 0 and len(r.stdout.strip().split("\n")) == nq * 3
+    # leftovers of an insert that never reached its commit point (rows and payload lines beyond vr_config's
+    # count): the next insert must land at id n + 1, not behind the orphans
+    cdir = tmp_path / "d" / "alice"
+    with open(cdir / "vr_vectors", "ab") as f:
+        f.write(np.full(3 * dim + 5, 7.0, np.float32).tobytes())       # three orphan rows and a torn fourth
+    with open(cdir / "vr_payloads", "a") as f:
+        f.write("orphan-a\norphan-b\ntorn")
+    line = ",".join(repr(float(v)) for v in rq[1]) + ";second-query"
+    assert run("-d", db, "-c", "alice", "-e", "INSERT", "-a", line).returncode == 0
+    assert os.path.getsize(cdir / "vr_vectors") == (n + 2) * dim * 4
+    assert open(cdir / "vr_payloads").read().split("\n")[n:] == ["the-query", "second-query", ""]
+    assert "count=3002" in open(cdir / "vr_config").read() and not os.path.exists(cdir / "vr_config.tmp")
+    r = run("-d", db, "-c", "alice", "-e", "SEARCHSIMILAR", "-a", "k=1;" + ",".join(repr(float(v)) for v in rq[1]))
+    assert r.returncode == 0 and r.stdout.split("\t")[2] == str(n + 1) and r.stdout.strip().endswith("second-query")
 
 
 @pytest.mark.gpu
@@ -140,3 +154,7 @@ def test_searchsimilar_over_a_multi_device_collection(tmp_path, oracle):
     ids = np.array([int(x[2]) for x in rows], dtype=np.uint64).reshape(nq, k)
     oi, _ = oracle.search(raw, rq, k, 0, 1)
     assert np.array_equal(ids, oi)
+    # one query, k = 5: nq*k odd (the per-shard blocks of the exchange must stay aligned)
+    r = run("-d", db, "-c", "c", "-e", "SEARCHSIMILAR", "-a", f"k=5;" + ",".join(repr(float(v)) for v in rq[1]), env=env)
+    assert r.returncode == 0, r.stderr
+    assert [int(l.split("\t")[2]) for l in r.stdout.strip().split("\n")] == oi[1].tolist()

@@ -430,7 +430,7 @@ void launch_sample_select(const float* d_scores, uint64_t score_ld, uint32_t n_s
 __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
     const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_fast,
     const float* __restrict__ cand_canon, const float* __restrict__ T, uint32_t kp, uint32_t k,
-    int metric, uint64_t id_offset, int eps_mode, float eps_c, const uint32_t* __restrict__ max_qn2_bits,
+    int metric, IdMap idmap, int eps_mode, float eps_c, const uint32_t* __restrict__ max_qn2_bits,
     const uint32_t* __restrict__ max_xn2_bits, uint64_t* __restrict__ out_ids,
     float* __restrict__ out_scores, uint32_t* __restrict__ status, float* __restrict__ max_err) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
     }
     for (uint32_t i = threadIdx.x; i < k; i += kSortThreads) {
         const uint64_t key = i < np2 ? sorted[i] : 0ull;
-        out_ids[(uint64_t)q * k + i] = key ? (uint64_t)key_row(key) + id_offset : UINT64_MAX;
+        out_ids[(uint64_t)q * k + i] = key ? idmap(key_row(key)) : UINT64_MAX;
         out_scores[(uint64_t)q * k + i] = key ? key_to_score_rt(key_skey(key), metric) : __uint_as_float(kScoreNoneBits);
     }
     if (threadIdx.x == 0) {
@@ -501,14 +501,14 @@ __global__ __launch_bounds__(kSortThreads) void final_topk_kernel(
 
 void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
                        const float* d_cand_canon, const float* d_T, int nq, uint32_t kp, uint32_t k,
-                       int metric, uint64_t id_offset, int eps_mode, float eps_c,
+                       int metric, const IdMap& idmap, int eps_mode, float eps_c,
                        const uint32_t* d_max_qn2_bits, const uint32_t* d_max_xn2_bits,
                        uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
                        float* d_max_err, hipStream_t s) {
     if (!nq) return;
     size_t lds = sort_lds_bytes(kp);
     if (lds < 2 * kRankSortMax * sizeof(uint64_t)) lds = 2 * kRankSortMax * sizeof(uint64_t);
-    final_topk_kernel<<<nq, kSortThreads, lds, s>>>(d_cand_rows, d_cand_fast, d_cand_canon, d_T, kp, k, metric, id_offset, eps_mode, eps_c, d_max_qn2_bits, d_max_xn2_bits, d_out_ids, d_out_scores, d_status, d_max_err);
+    final_topk_kernel<<<nq, kSortThreads, lds, s>>>(d_cand_rows, d_cand_fast, d_cand_canon, d_T, kp, k, metric, idmap, eps_mode, eps_c, d_max_qn2_bits, d_max_xn2_bits, d_out_ids, d_out_scores, d_status, d_max_err);
 }
 
 // ------------------------------------------------------------------ readback block
@@ -519,9 +519,11 @@ __global__ __launch_bounds__(256) void gather_readback_kernel(const uint32_t* __
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) out[i] = status[i];
     if (blockIdx.x == 0 && threadIdx.x < 4) {
         out[nq + threadIdx.x] = threadIdx.x < 3 ? flags3[threadIdx.x] : *max_xn2;
-        // the bad-value flag is consumed here, so that the next search in the stream (which may be
-        // enqueued before the host has looked at this one) starts from a clean flag
-        if (threadIdx.x == 0) flags3[0] = 0;
+        // the per-search scalars (bad-value flag, max |q|^2, max error) are consumed here, so that the
+        // next search in the stream (which may be enqueued before the host has looked at this one)
+        // starts from clean words.  They must NOT be cleared by the launch that accumulates into them
+        // (prep_queries_kernel's blocks atomicMax into max |q|^2 with no grid-wide order against a clear).
+        if (threadIdx.x < 3) flags3[threadIdx.x] = 0;
     }
 }
 
@@ -533,7 +535,7 @@ void launch_gather_readback(const uint32_t* d_status, uint32_t nq, uint32_t* d_f
 // ------------------------------------------------------------------ exact path output
 // keys: n <= kSelectChunk composite keys built from CANONICAL scores of one query.
 __global__ __launch_bounds__(kSortThreads) void keys_to_output_kernel(
-    const uint64_t* __restrict__ keys, uint32_t n, int metric, uint32_t k, uint64_t id_offset,
+    const uint64_t* __restrict__ keys, uint32_t n, int metric, uint32_t k, IdMap idmap,
     uint64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
     const uint32_t np2 = pow2_ceil(n < 2 ? 2 : n);
@@ -542,15 +544,15 @@ __global__ __launch_bounds__(kSortThreads) void keys_to_output_kernel(
     bitonic_sort_desc(skeys, np2);
     for (uint32_t i = threadIdx.x; i < k; i += kSortThreads) {
         const uint64_t key = i < np2 ? skeys[i] : 0ull;
-        out_ids[i] = key ? (uint64_t)key_row(key) + id_offset : UINT64_MAX;
+        out_ids[i] = key ? idmap(key_row(key)) : UINT64_MAX;
         out_scores[i] = key ? key_to_score_rt(key_skey(key), metric) : __uint_as_float(kScoreNoneBits);
     }
 }
 
 void launch_keys_to_output(const uint64_t* d_keys, uint64_t n, int metric, uint32_t k,
-                           uint64_t id_offset, uint64_t* d_out_ids, float* d_out_scores,
+                           const IdMap& idmap, uint64_t* d_out_ids, float* d_out_scores,
                            hipStream_t s) {
-    keys_to_output_kernel<<<1, kSortThreads, sort_lds_bytes(n), s>>>(d_keys, (uint32_t)n, metric, k, id_offset, d_out_ids, d_out_scores);
+    keys_to_output_kernel<<<1, kSortThreads, sort_lds_bytes(n), s>>>(d_keys, (uint32_t)n, metric, k, idmap, d_out_ids, d_out_scores);
 }
 
 // ------------------------------------------------------------------ shard merge (after the all-gather)
@@ -604,23 +606,16 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(int metric, const uint6
     }
 }
 
-// Multi-device handle: lists gathered from G shards hold LOCAL row indices; rows are dealt to the
-// shards in blocks of B (global r -> shard (r / B) % G, local (r / (B*G)) * B + r % B), so
-// global = ((local / B) * G + shard) * B + local % B.  Monotonic within a shard: a list sorted by
-// (score, local row) stays sorted by (score, global id).
-__global__ __launch_bounds__(256) void shard_ids_to_global_kernel(uint64_t* __restrict__ ids, uint64_t list_stride, uint32_t n_lists,
-                                                                  uint64_t per_list, uint64_t block_rows, uint64_t id_offset) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= per_list) return;
-    const uint32_t g = blockIdx.y;
-    uint64_t& id = ids[(uint64_t)g * list_stride + i];
-    if (id != UINT64_MAX) id = ((id / block_rows) * n_lists + g) * block_rows + id % block_rows + id_offset;
+__global__ __launch_bounds__(256) void fill_none_kernel(uint64_t* __restrict__ ids, float* __restrict__ scores, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        ids[i] = UINT64_MAX;
+        scores[i] = __uint_as_float(kScoreNoneBits);
+    }
 }
 
-void launch_shard_ids_to_global(uint64_t* d_ids, uint64_t list_stride, uint32_t n_lists, uint64_t per_list,
-                                uint64_t block_rows, uint64_t id_offset, hipStream_t s) {
-    if (!per_list || !n_lists) return;
-    shard_ids_to_global_kernel<<<dim3((unsigned)((per_list + 255) / 256), n_lists), 256, 0, s>>>(d_ids, list_stride, n_lists, per_list, block_rows, id_offset);
+void launch_fill_none(uint64_t* d_ids, float* d_scores, uint64_t n, hipStream_t s) {
+    if (!n) return;
+    fill_none_kernel<<<(unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), 256, 0, s>>>(d_ids, d_scores, n);
 }
 
 void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores, uint64_t list_stride_ids,

@@ -13,6 +13,8 @@
 // so the returned ids and score bits are identical to the CPU oracle's for every input.
 // There is no CPU fallback anywhere: without a gfx950 device every entry point fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen'ed when a multi-device handle is created
 
 #include <algorithm>
 #include <cmath>
@@ -172,8 +174,28 @@ struct vrod_index {
     // (r / (B*G)) * B + r % B), every shard is a complete single-device index of its own, and a
     // search runs on all of them at once, then gathers and merges on the first device.
     std::vector<vrod_index*> shards;
-    DevBuf gather;                       // [G][nq*k ids | nq*k scores] on shards[0]'s device
-    std::vector<DevBuf> sh_q, sh_ids, sh_scores;   // per shard, on its device
+    IdMap deal{};                        // a shard of a composite handle: how its local rows become global ids
+    // One group per DISTINCT device of the handle: the shards living on it, an exchange stream, the
+    // device's rank in the handle's RCCL communicator, and per pipeline slot the packed block this
+    // device contributes ([M][block]: one list per local shard, "no result" lists up to M = the
+    // largest group) and what it receives ([U][M][block]: every device's contribution).
+    struct DevGroup {
+        int device = 0;
+        std::vector<size_t> members;     // indices into shards
+        hipStream_t xstream = nullptr;
+        ncclComm_t comm = nullptr;
+        DevBuf send[2], recv[2];
+        size_t filled_nk[2] = {0, 0};    // nq*k the unused list slots of send[] were last filled for (+1)
+    };
+    std::vector<DevGroup> groups;
+    std::vector<std::pair<size_t, size_t>> shard_home;   // shard -> (group, position in the group)
+    bool use_rccl = false;
+    std::vector<DevBuf> sh_q[2];         // per slot, per shard: the batch's raw queries on the shard's device
+    struct CompPending {
+        uint32_t nq = 0, k = 0;
+        uint64_t* out_ids = nullptr;     // device pointers on groups[0].device
+        float* out_scores = nullptr;
+    } cslot[2];
     bool composite() const { return !shards.empty(); }
 
     size_t row_bytes() const { return (size_t)ld * esize; }
@@ -182,6 +204,13 @@ struct vrod_index {
 static int set_device(const vrod_index* idx) {
     HIP_TRY(hipSetDevice(idx->device));
     return VROD_OK;
+}
+
+// ids a search of this index reports: row + id_offset, or the dealing map of a composite handle's shard
+static IdMap idmap_of(const vrod_index* idx) {
+    IdMap m = idx->deal;
+    if (!m.block_rows) m.offset = idx->id_offset;
+    return m;
 }
 
 static int index_reserve(vrod_index* idx, uint64_t n_rows) {
@@ -194,13 +223,20 @@ static int index_reserve(vrod_index* idx, uint64_t n_rows) {
     hipError_t e = hipMalloc((void**)&nx, want * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(nc); return fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc norms: %s", hipGetErrorString(e)); }
     const size_t used = idx->count * idx->row_bytes();
+    hipError_t ce = hipSuccess;
     if (idx->count) {
-        HIP_TRY(hipMemcpyAsync(nc, idx->corpus, used, hipMemcpyDeviceToDevice, idx->stream));
-        HIP_TRY(hipMemcpyAsync(nx, idx->xnorm2, idx->count * sizeof(float), hipMemcpyDeviceToDevice, idx->stream));
+        ce = hipMemcpyAsync(nc, idx->corpus, used, hipMemcpyDeviceToDevice, idx->stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(nx, idx->xnorm2, idx->count * sizeof(float), hipMemcpyDeviceToDevice, idx->stream);
     }
-    HIP_TRY(hipMemsetAsync((char*)nc + used, 0, want * idx->row_bytes() - used, idx->stream));
-    HIP_TRY(hipMemsetAsync(nx + idx->count, 0, (want - idx->count) * sizeof(float), idx->stream));
-    HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (ce == hipSuccess) ce = hipMemsetAsync((char*)nc + used, 0, want * idx->row_bytes() - used, idx->stream);
+    if (ce == hipSuccess) ce = hipMemsetAsync(nx + idx->count, 0, (want - idx->count) * sizeof(float), idx->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(idx->stream);
+    if (ce != hipSuccess) {   // the old corpus stays in place; the new blocks are given back
+        (void)hipStreamSynchronize(idx->stream);
+        (void)hipFree(nc);
+        (void)hipFree(nx);
+        return fail(VROD_ERR_HIP, "growing the corpus failed: %s", hipGetErrorString(ce));
+    }
     if (idx->corpus) (void)hipFree(idx->corpus);
     if (idx->xnorm2) (void)hipFree(idx->xnorm2);
     if (idx->planes) { (void)hipFree(idx->planes); idx->planes = nullptr; idx->planes_cap = idx->planes_rows = 0; }   // rebuilt lazily
@@ -246,6 +282,10 @@ static int index_add(vrod_index* idx, const float* rows, uint64_t n, bool synthe
         VROD_TRY(index_reserve(idx, want));
     }
     const uint64_t count0 = idx->count;
+    // the max squared row norm is accumulated (atomicMax) by the very launches whose rows may be
+    // rejected: keep the value it had, so that a rejected add cannot widen (or, with an Inf row,
+    // void) the certificate bound of every later search
+    HIP_TRY(hipMemcpyAsync(&idx->flags[9], idx->max_xn2_bits, 4, hipMemcpyDeviceToDevice, idx->stream));
     const uint64_t chunk = std::min<uint64_t>(n, std::max<uint64_t>(1024, std::min<uint64_t>(kStageRows, (256ull << 20) / (idx->dim * 4ull))));
     VROD_TRY(idx->raw_stage.ensure(chunk * idx->dim * sizeof(float)));
     for (uint64_t done = 0; done < n; done += chunk) {
@@ -265,6 +305,7 @@ static int index_add(vrod_index* idx, const float* rows, uint64_t n, bool synthe
         idx->count = count0;
         (void)hipMemsetAsync((char*)idx->corpus + count0 * idx->row_bytes(), 0, n * idx->row_bytes(), idx->stream);
         (void)hipMemsetAsync(idx->xnorm2 + count0, 0, n * sizeof(float), idx->stream);
+        (void)hipMemcpyAsync(idx->max_xn2_bits, &idx->flags[9], 4, hipMemcpyDeviceToDevice, idx->stream);
         (void)hipStreamSynchronize(idx->stream);
         return rc;
     }
@@ -493,8 +534,10 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     qi.thr = mfma ? d_thr : nullptr;
     qi.thr_live_bits = worst_bits;
     qi.thr_pad_bits = worst_bits ^ 0x80000000u;
-    qi.zero_words = &P.flags[1];   // max |q|^2 bits, max err bits
-    qi.n_zero_words = 2;
+    // (flags[0..2] -- bad-value flag, max |q|^2 bits, max err bits -- are zero here: cleared by the
+    // read-back launch of the slot's previous search, never by the launch that accumulates into them)
+    qi.zero_words = nullptr;
+    qi.n_zero_words = 0;
     // pacing counters: 8 regions of 192 words behind the scalars, one per scan launch of this search
     constexpr uint32_t kPaceRegions = 8, kPaceWords = 192;
     uint32_t* pace_base = P.flags + 64;
@@ -656,7 +699,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         launch_rescore_candidates(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.q_f32.as<float>(), (int)nq,
                                   P.cand_rows.as<uint32_t>(), kp, P.cand_canon.as<float>(), s);
         launch_final_topk(P.cand_rows.as<uint32_t>(), P.cand_fast.as<float>(), P.cand_canon.as<float>(), d_T, (int)nq, kp, k,
-                          idx->metric, idx->id_offset, eps_mode, eps_c, &P.flags[1], idx->max_xn2_bits, d_out_ids, d_out_scores,
+                          idx->metric, idmap_of(idx), eps_mode, eps_c, &P.flags[1], idx->max_xn2_bits, d_out_ids, d_out_scores,
                           d_status, (float*)&P.flags[2], s);
     }
     launch_gather_readback(d_status, nq, P.flags, idx->max_xn2_bits, d_readback, s);
@@ -690,7 +733,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         const void* bufs[12] = {P.q_f32.p, P.q_lp.p, P.small.p, P.hist.p, P.scores.p, P.keys_a.p, P.cand_rows.p, P.cand_fast.p,
                                 P.cand_canon.p, P.h_readback, P.flags, idx->max_xn2_bits};
         memcpy(key.bufs, bufs, sizeof bufs);
-        key.N = N; key.id_offset = idx->id_offset; key.nq = nq; key.k = k; key.path = idx->path;
+        key.N = N; key.id_offset = idmap_of(idx).offset; key.nq = nq; key.k = k; key.path = idx->path;
     }
     Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
     hipStream_t s = P.stream;
@@ -809,7 +852,7 @@ static int search_complete(vrod_index* idx, Pending& P) {
             VROD_TRY(select_chain(idx, P, P.scores.as<float>(), score_ld, N, g, kx, &keys, &kld, &kn));
             for (int i = 0; i < g; ++i) {
                 const uint32_t qi = failed[f0 + i];
-                launch_keys_to_output(keys + (size_t)i * kld, kn, idx->metric, k, idx->id_offset, P.out_ids + (size_t)qi * k,
+                launch_keys_to_output(keys + (size_t)i * kld, kn, idx->metric, k, idmap_of(idx), P.out_ids + (size_t)qi * k,
                                       P.out_scores + (size_t)qi * k, s);
             }
             HIP_TRY(hipGetLastError());
@@ -840,9 +883,9 @@ static int search_begin(vrod_index* idx, const float* d_queries_raw, uint32_t nq
     }
     int rc = search_enqueue(idx, P, d_queries_raw, nq, k, d_out_ids, d_out_scores);
     if (rc != VROD_OK) {
-        // a half-enqueued search: drain the stream, consume the bad-value flag, leave the slot free
+        // a half-enqueued search: drain the stream, consume the per-search scalars, leave the slot free
         (void)hipStreamSynchronize(P.stream);
-        (void)hipMemsetAsync(&P.flags[0], 0, 4, P.stream);
+        (void)hipMemsetAsync(&P.flags[0], 0, 12, P.stream);
         (void)hipStreamSynchronize(P.stream);
         return rc;
     }
@@ -906,6 +949,10 @@ static uint64_t local_row_of(const vrod_index* idx, uint64_t r) {
 
 static int composite_add(vrod_index* idx, const float* rows, uint64_t n, bool synthetic, uint64_t seed, uint64_t first_row) {
     const uint64_t count0 = idx->count;
+    for (vrod_index* sh : idx->shards) {   // what a roll-back restores (see index_add)
+        VROD_TRY(set_device(sh));
+        HIP_TRY(hipMemcpyAsync(&sh->flags[10], sh->max_xn2_bits, 4, hipMemcpyDeviceToDevice, sh->stream));
+    }
     int rc = for_each_piece(idx, count0, n, [&](size_t g, uint64_t r, uint64_t m) {
         vrod_index* sh = idx->shards[g];
         if (sh->count != local_row_of(idx, r)) return fail(VROD_ERR_INTERNAL, "shard %zu is out of step", g);
@@ -921,9 +968,11 @@ static int composite_add(vrod_index* idx, const float* rows, uint64_t n, bool sy
                 (void)hipSetDevice(sh->device);
                 (void)hipMemsetAsync((char*)sh->corpus + want * sh->row_bytes(), 0, (sh->count - want) * sh->row_bytes(), sh->stream);
                 (void)hipMemsetAsync(sh->xnorm2 + want, 0, (sh->count - want) * sizeof(float), sh->stream);
-                (void)hipStreamSynchronize(sh->stream);
                 sh->count = want;
             }
+            (void)hipSetDevice(sh->device);
+            (void)hipMemcpyAsync(sh->max_xn2_bits, &sh->flags[10], 4, hipMemcpyDeviceToDevice, sh->stream);
+            (void)hipStreamSynchronize(sh->stream);
         }
         return rc;
     }
@@ -937,36 +986,182 @@ static int composite_get_rows(vrod_index* idx, uint64_t first, uint64_t n, float
     });
 }
 
-// queries: host pointer (from_host) or device pointer on shards[0]'s device; outputs likewise
-static int composite_search(vrod_index* idx, const float* queries, bool from_host, uint32_t nq, uint32_t k,
-                            uint64_t* out_ids, float* out_scores) {
-    const size_t G = idx->shards.size();
+// ---- RCCL, bound at run time.  A multi-device handle exchanges the per-shard top-k with ONE
+// ncclAllGather per device inside a group call ("single process, ncclCommInitAll, one
+// stream per device").  librccl is dlopen'ed when the first such handle is created: a process that
+// already holds it (PyTorch ships one with the same soname) shares that copy, and single-device
+// handles never load it.
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;   // why it could not be loaded
+};
+static RcclApi& rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    const char* names[] = {getenv("VROD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !n[0]) continue;
+        api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (api.h) break;
+        api.why = dlerror();
+    }
+    if (!api.h) return api;
+    bool ok = true;
+    auto sym = [&](const char* name) { void* f = dlsym(api.h, name); if (!f) { ok = false; api.why = std::string("missing symbol ") + name; } return f; };
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(api.h); api.h = nullptr; }
+    return api;
+}
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return fail(VROD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl_api().GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// Groups the shards by device and opens the communicator over the distinct devices.
+static int composite_open_exchange(vrod_index* idx) {
+    for (size_t g = 0; g < idx->shards.size(); ++g) {
+        const int dev = idx->shards[g]->device;
+        size_t u = 0;
+        while (u < idx->groups.size() && idx->groups[u].device != dev) ++u;
+        if (u == idx->groups.size()) { idx->groups.emplace_back(); idx->groups.back().device = dev; }
+        idx->shard_home.push_back({u, idx->groups[u].members.size()});
+        idx->groups[u].members.push_back(g);
+    }
+    for (auto& G : idx->groups) {
+        HIP_TRY(hipSetDevice(G.device));
+        HIP_TRY(hipStreamCreateWithFlags(&G.xstream, hipStreamNonBlocking));
+    }
+    const char* e = getenv("VROD_RCCL");
+    idx->use_rccl = !(e && e[0] == '0');   // VROD_RCCL=0: peer copies to the first device instead
+    if (idx->use_rccl) {
+        RcclApi& api = rccl_api();
+        if (!api.h) return fail(VROD_ERR_UNSUPPORTED, "a multi-device handle exchanges its results over RCCL, and librccl could not be loaded (%s); "
+                                "set VROD_RCCL_LIB to its path, or VROD_RCCL=0 for peer copies", api.why.c_str());
+        std::vector<int> devs;
+        for (auto& G : idx->groups) devs.push_back(G.device);
+        std::vector<ncclComm_t> comms(devs.size(), nullptr);
+        NCCL_TRY(api.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        for (size_t u = 0; u < devs.size(); ++u) idx->groups[u].comm = comms[u];
+    }
+    return VROD_OK;
+}
+
+static size_t composite_lists_per_device(const vrod_index* idx) {
+    size_t m = 1;
+    for (auto& G : idx->groups) m = std::max(m, G.members.size());
+    return m;
+}
+// one device's packed result block: nk ids (u64) then nk scores (f32), padded so that every list of
+// the gathered buffer starts 16-B aligned whatever the parity of nq*k
+static size_t composite_block_bytes(size_t nk) { return round_up(nk * 12, 16); }
+
+// The shards' searches of the slot being begun: queries from the host (from_host), from device
+// memory of the first device (d/h pointer `queries`), or rows of the synthetic stream (`queries`
+// null).  Returns with every shard's search enqueued, or with none pending on an error.
+static int composite_begin(vrod_index* idx, const float* queries, bool from_host, uint64_t seed, uint64_t first_row,
+                           uint32_t nq, uint32_t k, uint64_t* out_ids, float* out_scores, void* caller_stream) {
+    if (idx->n_pending() >= 2) return fail(VROD_ERR_INVALID_ARG, "two searches are already pending: call vrod_search_end first");
+    const uint32_t c = idx->n_begun & 1;
+    vrod_index::CompPending& CP = idx->cslot[c];
+    CP.nq = nq; CP.k = k; CP.out_ids = out_ids; CP.out_scores = out_scores;
+    const size_t G = idx->shards.size(), U = idx->groups.size();
+    const size_t nk = (size_t)nq * k, block = composite_block_bytes(nk), M = composite_lists_per_device(idx);
+    const size_t qbytes = (size_t)nq * idx->dim * 4;
+    idx->sh_q[c].resize(G);
+    if (nq) {
+        for (size_t u = 0; u < U; ++u) {
+            vrod_index::DevGroup& D = idx->groups[u];
+            VROD_TRY(set_device(idx->shards[D.members[0]]));
+            const void* before = D.send[c].p;
+            VROD_TRY(D.send[c].ensure(M * block));
+            VROD_TRY(D.recv[c].ensure(U * M * block));
+            if (D.members.size() < M && (D.send[c].p != before || D.filled_nk[c] != nk + 1)) {
+                // list slots no shard of this device writes: "no result" entries, which the merge skips
+                for (size_t m = D.members.size(); m < M; ++m)
+                    launch_fill_none((uint64_t*)((char*)D.send[c].p + m * block), (float*)((char*)D.send[c].p + m * block + nk * 8), nk, D.xstream);
+                HIP_TRY(hipStreamSynchronize(D.xstream));
+                D.filled_nk[c] = nk + 1;
+            }
+        }
+        if (queries && !from_host) {   // the caller's stream (first device) produced the queries
+            VROD_TRY(set_device(idx->shards[idx->groups[0].members[0]]));
+            if (!idx->caller_ev) HIP_TRY(hipEventCreateWithFlags(&idx->caller_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(idx->caller_ev, (hipStream_t)caller_stream));
+        }
+    }
+    int rc = VROD_OK;
+    size_t begun = 0;
+    for (size_t g = 0; g < G && rc == VROD_OK; ++g) {
+        vrod_index* sh = idx->shards[g];
+        const auto [u, m] = idx->shard_home[g];
+        if ((rc = set_device(sh)) != VROD_OK) break;
+        sh->path = idx->path;
+        sh->profiling = idx->profiling;
+        sh->deal = IdMap{idx->id_offset, (uint32_t)kShardBlock, (uint32_t)g, (uint32_t)G};
+        uint64_t* oi = nq ? (uint64_t*)((char*)idx->groups[u].send[c].p + m * block) : nullptr;
+        float* os = nq ? (float*)((char*)idx->groups[u].send[c].p + m * block + nk * 8) : nullptr;
+        hipStream_t ss = next_slot(sh).stream;
+        const float* q = nullptr;
+        if (nq) {
+            if ((rc = idx->sh_q[c][g].ensure(std::max<size_t>(qbytes, 4))) != VROD_OK) break;
+            q = idx->sh_q[c][g].as<float>();
+            hipError_t e = hipSuccess;
+            if (!queries) {
+                launch_synth_rows(seed, first_row, nq, idx->dim, idx->sh_q[c][g].as<float>(), ss);
+            } else if (from_host) {
+                e = hipMemcpyAsync(idx->sh_q[c][g].p, queries, qbytes, hipMemcpyHostToDevice, ss);
+            } else {
+                e = hipStreamWaitEvent(ss, idx->caller_ev, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(idx->sh_q[c][g].p, queries, qbytes, hipMemcpyDefault, ss);
+            }
+            if (e != hipSuccess) { rc = fail(VROD_ERR_HIP, "queries to device %d: %s", sh->device, hipGetErrorString(e)); break; }
+        }
+        rc = search_begin(sh, q, nq, k, oi, os);
+        if (rc == VROD_OK) ++begun;
+    }
+    if (rc != VROD_OK) {   // a search begun must be ended: nothing stays pending behind an error
+        const std::string why = g_last_error;
+        for (size_t g = 0; g < begun; ++g) { (void)set_device(idx->shards[g]); (void)search_end(idx->shards[g]); }
+        g_last_error = why;
+        return rc;
+    }
+    idx->n_begun++;
+    return VROD_OK;
+}
+
+// Complete the oldest composite search: every shard's search, then the exchange (RCCL all-gather of
+// one packed block per device, or peer copies with VROD_RCCL=0) and the merge on the first device.
+// to_host: the caller's outputs are host memory (vrod_search).
+static int composite_end(vrod_index* idx, uint64_t* host_ids, float* host_scores) {
+    if (idx->n_pending() == 0) return fail(VROD_ERR_INVALID_ARG, "no search is pending");
+    const uint32_t c = idx->n_ended & 1;
+    idx->n_ended++;
+    vrod_index::CompPending& CP = idx->cslot[c];
+    const uint32_t nq = CP.nq, k = CP.k;
+    const size_t G = idx->shards.size(), U = idx->groups.size();
     idx->stats = vrod_search_stats{};
     idx->stats.nq = nq;
     idx->stats.k = k;
-    if (!nq) return VROD_OK;
-    const size_t qbytes = (size_t)nq * idx->dim * 4, nk = (size_t)nq * k;
-    idx->sh_q.resize(G); idx->sh_ids.resize(G); idx->sh_scores.resize(G);
     int rc = VROD_OK;
-    // enqueue on every device, then complete: the shards scan concurrently
     for (size_t g = 0; g < G; ++g) {
         vrod_index* sh = idx->shards[g];
-        if ((rc = set_device(sh)) != VROD_OK || (rc = idx->sh_q[g].ensure(qbytes)) != VROD_OK ||
-            (rc = idx->sh_ids[g].ensure(nk * 8)) != VROD_OK || (rc = idx->sh_scores[g].ensure(nk * 4)) != VROD_OK) break;
-        if (hipMemcpyAsync(idx->sh_q[g].p, queries, qbytes, from_host ? hipMemcpyHostToDevice : hipMemcpyDefault, next_slot(sh).stream) != hipSuccess) {
-            rc = fail(VROD_ERR_HIP, "query upload to device %d failed", sh->device);
-            break;
-        }
-        sh->path = idx->path;
-        sh->profiling = idx->profiling;
-        rc = search_begin(sh, idx->sh_q[g].as<float>(), nq, k, idx->sh_ids[g].as<uint64_t>(), idx->sh_scores[g].as<float>());
-        if (rc != VROD_OK) break;
-    }
-    for (size_t g = 0; g < G; ++g) {
-        if (idx->shards[g]->n_pending() == 0) continue;   // not begun (an earlier shard failed to enqueue)
-        vrod_index* sh = idx->shards[g];
-        VROD_TRY(set_device(sh));
-        const int r = search_end(sh);     // every begun search is ended, whatever the others return
+        const int r0 = set_device(sh);
+        const int r = r0 != VROD_OK ? r0 : search_end(sh);     // every begun search is ended, whatever the others return
         if (r != VROD_OK && rc == VROD_OK) rc = r;
         const vrod_search_stats& st = sh->stats;
         idx->stats.path = st.path; idx->stats.kprime = st.kprime;
@@ -979,29 +1174,54 @@ static int composite_search(vrod_index* idx, const float* queries, bool from_hos
         idx->stats.max_fast_err = std::max(idx->stats.max_fast_err, st.max_fast_err);
         idx->stats.eps_bound = std::max(idx->stats.eps_bound, st.eps_bound);
     }
-    if (rc != VROD_OK) return rc;
-    // gather the per-shard lists on the first device (packed: ids | scores per shard), translate
-    // local rows to global ids, merge
-    vrod_index* s0 = idx->shards[0];
-    VROD_TRY(set_device(s0));
-    const size_t block = nk * 12;
-    VROD_TRY(idx->gather.ensure(G * block));
-    VROD_TRY(idx->out_ids.ensure(nk * 8));
-    VROD_TRY(idx->out_scores.ensure(nk * 4));
-    for (size_t g = 0; g < G; ++g) {
-        char* dst = (char*)idx->gather.p + g * block;
-        HIP_TRY(hipMemcpyPeerAsync(dst, s0->device, idx->sh_ids[g].p, idx->shards[g]->device, nk * 8, s0->stream));
-        HIP_TRY(hipMemcpyPeerAsync(dst + nk * 8, s0->device, idx->sh_scores[g].p, idx->shards[g]->device, nk * 4, s0->stream));
+    idx->stats.exchange = idx->use_rccl ? 1u : 2u;
+    if (rc != VROD_OK || !nq) return rc;
+    // every shard's list is complete in its device's send block (the host has seen each search end)
+    const size_t nk = (size_t)nq * k, block = composite_block_bytes(nk), M = composite_lists_per_device(idx);
+    vrod_index::DevGroup& D0 = idx->groups[0];
+    if (idx->use_rccl) {
+        RcclApi& api = rccl_api();
+        NCCL_TRY(api.GroupStart());
+        for (size_t u = 0; u < U; ++u) {
+            vrod_index::DevGroup& D = idx->groups[u];
+            const ncclResult_t r = api.AllGather(D.send[c].p, D.recv[c].p, M * block, ncclUint8, D.comm, D.xstream);
+            if (r != ncclSuccess) { (void)api.GroupEnd(); return fail(VROD_ERR_HIP, "ncclAllGather failed: %s", api.GetErrorString(r)); }
+        }
+        NCCL_TRY(api.GroupEnd());
+    } else {
+        HIP_TRY(hipSetDevice(D0.device));
+        for (size_t u = 0; u < U; ++u)
+            HIP_TRY(hipMemcpyPeerAsync((char*)D0.recv[c].p + u * M * block, D0.device, idx->groups[u].send[c].p, idx->groups[u].device, M * block, D0.xstream));
     }
-    launch_shard_ids_to_global((uint64_t*)idx->gather.p, block / 8, (uint32_t)G, nk, kShardBlock, idx->id_offset, s0->stream);
-    launch_merge_topk(idx->metric, (const uint64_t*)idx->gather.p, (const float*)((const char*)idx->gather.p + nk * 8), block / 8, block / 4,
-                      (uint32_t)G, nq, k, idx->out_ids.as<uint64_t>(), idx->out_scores.as<float>(), s0->stream);
+    HIP_TRY(hipSetDevice(D0.device));
+    uint64_t* oi = CP.out_ids;
+    float* os = CP.out_scores;
+    if (host_ids) {
+        VROD_TRY(idx->out_ids.ensure(nk * 8));
+        VROD_TRY(idx->out_scores.ensure(nk * 4));
+        oi = idx->out_ids.as<uint64_t>();
+        os = idx->out_scores.as<float>();
+    }
+    launch_merge_topk(idx->metric, (const uint64_t*)D0.recv[c].p, (const float*)((const char*)D0.recv[c].p + nk * 8), block / 8, block / 4,
+                      (uint32_t)(U * M), nq, k, oi, os, D0.xstream);
     HIP_TRY(hipGetLastError());
-    const hipMemcpyKind kind = from_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    HIP_TRY(hipMemcpyAsync(out_ids, idx->out_ids.p, nk * 8, kind, s0->stream));
-    HIP_TRY(hipMemcpyAsync(out_scores, idx->out_scores.p, nk * 4, kind, s0->stream));
-    HIP_TRY(hipStreamSynchronize(s0->stream));
+    if (host_ids) {
+        HIP_TRY(hipMemcpyAsync(host_ids, oi, nk * 8, hipMemcpyDeviceToHost, D0.xstream));
+        HIP_TRY(hipMemcpyAsync(host_scores, os, nk * 4, hipMemcpyDeviceToHost, D0.xstream));
+    }
+    // the other devices' all-gathers read their send blocks: done before the slot is reused
+    for (size_t u = U; u-- > 0;) {
+        HIP_TRY(hipSetDevice(idx->groups[u].device));
+        HIP_TRY(hipStreamSynchronize(idx->groups[u].xstream));
+    }
     return VROD_OK;
+}
+
+static int composite_search(vrod_index* idx, const float* queries, bool from_host, uint64_t seed, uint64_t first_row, uint32_t nq, uint32_t k,
+                            uint64_t* out_ids, float* out_scores, void* caller_stream) {
+    if (idx->n_pending()) return fail(VROD_ERR_INVALID_ARG, "a synchronous search while a search is pending: call vrod_search_end first");
+    VROD_TRY(composite_begin(idx, queries, from_host, seed, first_row, nq, k, from_host ? nullptr : out_ids, from_host ? nullptr : out_scores, caller_stream));
+    return composite_end(idx, from_host ? out_ids : nullptr, from_host ? out_scores : nullptr);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -1031,6 +1251,8 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
         }
         c->device = c->shards[0]->device;
         c->ld = c->shards[0]->ld; c->esize = c->shards[0]->esize;
+        const int rc = composite_open_exchange(c);
+        if (rc != VROD_OK) { const std::string why = g_last_error; vrod_index_destroy(c); g_last_error = why; return rc; }
         *out = c;
         return VROD_OK;
     }
@@ -1082,12 +1304,22 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
 int vrod_index_destroy(vrod_index* idx) {
     if (!idx) return VROD_OK;
     if (idx->composite()) {
+        while (idx->n_pending()) (void)composite_end(idx, nullptr, nullptr);   // a begun search is ended before its buffers go
         for (size_t g = 0; g < idx->shards.size(); ++g) {
             (void)hipSetDevice(idx->shards[g]->device);
-            if (g < idx->sh_q.size()) { idx->sh_q[g].release(); idx->sh_ids[g].release(); idx->sh_scores[g].release(); }
+            for (int c = 0; c < 2; ++c)
+                if (g < idx->sh_q[c].size()) idx->sh_q[c][g].release();
+        }
+        for (auto& D : idx->groups) {
+            (void)hipSetDevice(D.device);
+            if (D.xstream) (void)hipStreamSynchronize(D.xstream);
+            if (D.comm) (void)rccl_api().CommDestroy(D.comm);
+            for (int c = 0; c < 2; ++c) { D.send[c].release(); D.recv[c].release(); }
+            if (D.xstream) (void)hipStreamDestroy(D.xstream);
         }
         (void)hipSetDevice(idx->device);
-        idx->gather.release(); idx->out_ids.release(); idx->out_scores.release(); idx->raw_stage.release();
+        if (idx->caller_ev) (void)hipEventDestroy(idx->caller_ev);
+        idx->out_ids.release(); idx->out_scores.release(); idx->raw_stage.release();
         for (vrod_index* sh : idx->shards) vrod_index_destroy(sh);
         delete idx;
         return VROD_OK;
@@ -1184,10 +1416,8 @@ static int check_search_args(vrod_index* idx, const void* q, uint32_t nq, uint32
 int vrod_search_device(vrod_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
                        uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, d_queries, nq, k, d_out_ids, d_out_scores));
-    if (idx->composite()) {   // pointers on the first device of the handle
-        if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        return composite_search(idx, d_queries, false, nq, k, d_out_ids, d_out_scores);
-    }
+    if (idx->composite())   // pointers on the first device of the handle
+        return composite_search(idx, d_queries, false, 0, 0, nq, k, d_out_ids, d_out_scores, stream);
     VROD_TRY(require_idle(idx, "vrod_search_device"));
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));   // the caller's inputs are ready
@@ -1197,7 +1427,7 @@ int vrod_search_device(vrod_index* idx, const float* d_queries, uint32_t nq, uin
 int vrod_search_begin_device(vrod_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
                              uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, d_queries, nq, k, d_out_ids, d_out_scores));
-    if (idx->composite()) return fail(VROD_ERR_UNSUPPORTED, "the pipelined form is per device: a multi-device handle searches all its devices in one call");
+    if (idx->composite()) return composite_begin(idx, d_queries, false, 0, 0, nq, k, d_out_ids, d_out_scores, stream);
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));
     return search_begin(idx, d_queries, nq, k, d_out_ids, d_out_scores);
@@ -1206,7 +1436,7 @@ int vrod_search_begin_device(vrod_index* idx, const float* d_queries, uint32_t n
 int vrod_search_begin_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t first_row, uint32_t nq,
                                        uint32_t k, uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, (void*)1, nq, k, d_out_ids, d_out_scores));
-    if (idx->composite()) return fail(VROD_ERR_UNSUPPORTED, "the pipelined form is per device: a multi-device handle searches all its devices in one call");
+    if (idx->composite()) return composite_begin(idx, nullptr, false, seed, first_row, nq, k, d_out_ids, d_out_scores, stream);
     if (idx->n_pending() >= 2) return fail(VROD_ERR_INVALID_ARG, "two searches are already pending: call vrod_search_end first");
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));
@@ -1220,7 +1450,7 @@ int vrod_search_begin_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t 
 
 int vrod_search_end(vrod_index* idx) {
     if (!idx) return fail(VROD_ERR_INVALID_ARG, "idx is null");
-    if (idx->composite()) return fail(VROD_ERR_INVALID_ARG, "no search is pending");
+    if (idx->composite()) return composite_end(idx, nullptr, nullptr);
     VROD_TRY(set_device(idx));
     return search_end(idx);
 }
@@ -1234,15 +1464,8 @@ int vrod_search_pending(const vrod_index* idx, uint32_t* out_pending) {
 int vrod_search_synthetic_device(vrod_index* idx, uint64_t seed, uint64_t first_row, uint32_t nq,
                                  uint32_t k, uint64_t* d_out_ids, float* d_out_scores, void* stream) {
     VROD_TRY(check_search_args(idx, (void*)1, nq, k, d_out_ids, d_out_scores));
-    if (idx->composite()) {
-        vrod_index* s0 = idx->shards[0];
-        VROD_TRY(set_device(s0));
-        if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        VROD_TRY(idx->raw_stage.ensure((size_t)std::max<uint32_t>(nq, 1) * idx->dim * 4));
-        launch_synth_rows(seed, first_row, nq, idx->dim, idx->raw_stage.as<float>(), s0->stream);
-        HIP_TRY(hipStreamSynchronize(s0->stream));
-        return composite_search(idx, idx->raw_stage.as<float>(), false, nq, k, d_out_ids, d_out_scores);
-    }
+    if (idx->composite())   // every device generates the batch's queries itself: nothing to copy
+        return composite_search(idx, nullptr, false, seed, first_row, nq, k, d_out_ids, d_out_scores, stream);
     VROD_TRY(require_idle(idx, "vrod_search_synthetic_device"));
     VROD_TRY(set_device(idx));
     VROD_TRY(order_after_caller(idx, stream));
@@ -1256,7 +1479,7 @@ int vrod_search(vrod_index* idx, const float* queries, uint32_t nq, uint32_t k, 
                 float* out_scores) {
     VROD_TRY(check_search_args(idx, queries, nq, k, out_ids, out_scores));
     if (!nq) return VROD_OK;
-    if (idx->composite()) return composite_search(idx, queries, true, nq, k, out_ids, out_scores);
+    if (idx->composite()) return composite_search(idx, queries, true, 0, 0, nq, k, out_ids, out_scores, nullptr);
     VROD_TRY(require_idle(idx, "vrod_search"));
     VROD_TRY(set_device(idx));
     Pending& P = next_slot(idx);

@@ -6,6 +6,22 @@
 
 namespace vrod {
 
+// How a shard's local row index becomes the id the caller sees.  Single-device index: row + offset.
+// Shard `shard` of a multi-device handle (rows dealt to `n_shards` shards in blocks of `block_rows`:
+// global r -> shard (r / B) % G, local (r / (B*G)) * B + r % B):
+//   id = ((row / B) * G + shard) * B + row % B + offset
+// -- monotonic within a shard, so a list sorted by (score, local row) stays sorted by (score, id).
+struct IdMap {
+    uint64_t offset = 0;
+    uint32_t block_rows = 0;   // 0: identity mapping
+    uint32_t shard = 0, n_shards = 1;
+    __host__ __device__ inline uint64_t operator()(uint32_t row) const {
+        if (block_rows == 0) return (uint64_t)row + offset;
+        const uint64_t b = row / block_rows, r = row % block_rows;
+        return (b * n_shards + shard) * block_rows + r + offset;
+    }
+};
+
 // ---- kernels_prep.hip
 void launch_synth_rows(uint64_t seed, uint64_t first_row, uint64_t n, uint32_t dim, float* d_out,
                        hipStream_t s);
@@ -33,8 +49,6 @@ void launch_prep_queries(const float* d_in, uint32_t nq, uint32_t nq_pad, uint32
                          uint32_t* d_max_bits, const QueryInit& init, hipStream_t s);
 // tail of a search: status[nq] followed by {bad flag, max |q|^2 bits, max err bits, max |x|^2 bits}
 // gathered into one contiguous block so that the host needs ONE device-to-host copy
-void launch_shard_ids_to_global(uint64_t* d_ids, uint64_t list_stride, uint32_t n_lists, uint64_t per_list,
-                                uint64_t block_rows, uint64_t id_offset, hipStream_t s);
 void launch_gather_readback(const uint32_t* d_status, uint32_t nq, uint32_t* d_flags3, const uint32_t* d_max_xn2,
                             uint32_t* d_out, hipStream_t s);
 void launch_row_fastnorm(const void* d_rows, int dtype, uint64_t n, uint32_t ld, float* d_xn2,
@@ -90,14 +104,14 @@ void launch_list_compact(uint2* d_lists, uint32_t* d_counts, uint32_t cap, int n
 // (exact, 3-pass radix select on the order-preserving key).  One block per query.
 void launch_sample_select(const float* d_scores, uint64_t score_ld, uint32_t n_sample, int nq,
                           int metric, uint32_t j, float* d_thr, hipStream_t s);
-// Final: canonical scores of the kp candidates -> sorted top-k (ids u64 = row + id_offset),
+// Final: canonical scores of the kp candidates -> sorted top-k (ids u64 = idmap(row)),
 // certificate per query in d_status bit 0 (1 = NOT certified).
 // The certificate's bound on |fast - canonical| is formed on the device from the max squared
 // norms (float bits) of the queries and of the corpus:  eps_mode 0: c * |q| * |x|  (dot paths),
 // 1: c relative to T (direct L2),  2: c * (|q| + |x|)^2 (L2 through the norm expansion).
 void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
                        const float* d_cand_canon, const float* d_T, int nq, uint32_t kp, uint32_t k,
-                       int metric, uint64_t id_offset, int eps_mode, float eps_c,
+                       int metric, const IdMap& idmap, int eps_mode, float eps_c,
                        const uint32_t* d_max_qn2_bits, const uint32_t* d_max_xn2_bits,
                        uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
                        float* d_max_err, hipStream_t s);
@@ -105,9 +119,12 @@ void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
 // Exact path: canonical scores (implicit ids) -> exact top-k, via the same select chain with
 // composite keys (ties -> smaller id).  Writes one query's output row.
 void launch_keys_to_output(const uint64_t* d_keys, uint64_t n, int metric, uint32_t k,
-                           uint64_t id_offset, uint64_t* d_out_ids, float* d_out_scores,
+                           const IdMap& idmap, uint64_t* d_out_ids, float* d_out_scores,
                            hipStream_t s);
 
+// Fill a result block with "no result" (ids = UINT64_MAX, scores = NaN): the empty list slots of
+// the multi-device exchange.
+void launch_fill_none(uint64_t* d_ids, float* d_scores, uint64_t n, hipStream_t s);
 // Merge n_lists per-shard results into one. List l's ids start at d_ids + l*list_stride_ids
 // (elements), its scores at d_scores + l*list_stride_scores; each is [nq][k].
 void launch_merge_topk(int metric, const uint64_t* d_ids, const float* d_scores, uint64_t list_stride_ids,

@@ -64,11 +64,51 @@ Collection::~Collection() {
     if (index_) vrod_index_destroy(index_);
 }
 
+// vr_config is the commit point of an insert: written to a temporary file and renamed over the old
+// one, so a reader sees either the old count or the new one, never a torn file.
 void Collection::save_config() const {
-    std::ofstream f(join(dir_, "vr_config"), std::ios::trunc);
-    if (!f) throw IoError(IoError::Other, "cannot write vr_config of collection '" + name_ + "'");
-    f << "dim=" << cfg_.dim << "\nmetric=" << metric_name(cfg_.metric) << "\ndtype=" << dtype_name(cfg_.dtype)
-      << "\ncount=" << cfg_.count << "\n";
+    const std::string path = join(dir_, "vr_config"), tmp = path + ".tmp";
+    {
+        std::ofstream f(tmp, std::ios::trunc);
+        if (!f) throw IoError(IoError::Other, "cannot write vr_config of collection '" + name_ + "'");
+        f << "dim=" << cfg_.dim << "\nmetric=" << metric_name(cfg_.metric) << "\ndtype=" << dtype_name(cfg_.dtype)
+          << "\ncount=" << cfg_.count << "\n";
+        f.flush();
+        if (!f) throw IoError(IoError::Other, "short write to vr_config of collection '" + name_ + "'");
+    }
+    if (::rename(tmp.c_str(), path.c_str()) != 0)
+        throw IoError(IoError::Other, "cannot replace vr_config of collection '" + name_ + "'");
+}
+
+// Rows beyond `count` are leftovers of an insert that never reached its commit point (a failed or
+// short write, a crash before save_config): cut vr_vectors back to count rows and vr_payloads to
+// count lines, so that the next append lands where vr_config says the collection ends.  Once per
+// process: a completed insert leaves the files consistent.
+void Collection::trim_to_count() {
+    if (trimmed_) return;
+    const std::string vpath = join(dir_, "vr_vectors"), ppath = join(dir_, "vr_payloads");
+    struct stat sb;
+    const uint64_t want = cfg_.count * (uint64_t)cfg_.dim * 4ull;
+    if (::stat(vpath.c_str(), &sb) == 0 && (uint64_t)sb.st_size > want && ::truncate(vpath.c_str(), (off_t)want) != 0)
+        throw IoError(IoError::Other, "cannot trim vr_vectors of '" + name_ + "'");
+    if (::stat(ppath.c_str(), &sb) == 0 && sb.st_size > 0) {
+        std::ifstream f(ppath, std::ios::binary);
+        uint64_t lines = 0, off = 0;
+        std::vector<char> buf(1 << 20);
+        bool cut = false;
+        while (f && !cut) {
+            f.read(buf.data(), (std::streamsize)buf.size());
+            const std::streamsize got = f.gcount();
+            for (std::streamsize i = 0; i < got; ++i) {
+                if (lines == cfg_.count) { cut = true; off += (uint64_t)i; break; }
+                if (buf[(size_t)i] == '\n') ++lines;
+            }
+            if (!cut) off += (uint64_t)got;
+        }
+        if (cut && off < (uint64_t)sb.st_size && ::truncate(ppath.c_str(), (off_t)off) != 0)
+            throw IoError(IoError::Other, "cannot trim vr_payloads of '" + name_ + "'");
+    }
+    trimmed_ = true;
 }
 
 void Collection::load_config() {
@@ -133,20 +173,41 @@ void Collection::insert(const std::vector<float>& rows, uint32_t dim, const std:
     // device first (it validates NaN/Inf), then disk
     if (index_ || cfg_.count > 0) ensure_resident();
     if (!index_) check(create_index(&index_, cfg_.dim, cfg_.dtype, cfg_.metric), "vrod_index_create");
+    trim_to_count();
+    const uint64_t count0 = cfg_.count;
     check(vrod_index_add(index_, rows.data(), n), "vrod_index_add");
-    {
-        std::ofstream f(join(dir_, "vr_vectors"), std::ios::binary | std::ios::app);
-        if (!f) throw IoError(IoError::Other, "cannot append to vr_vectors of '" + name_ + "'");
-        f.write(reinterpret_cast<const char*>(rows.data()), (std::streamsize)(rows.size() * 4));
-    }
-    {
-        std::ofstream f(join(dir_, "vr_payloads"), std::ios::app);
-        for (uint64_t i = 0; i < n; ++i) f << (i < payloads.size() ? payloads[i] : std::string()) << "\n";
+    // disk: vectors, payloads, then vr_config (the commit point).  A failure before the commit leaves
+    // orphans beyond `count`, which the next process trims; this process must not go on with a device
+    // copy the disk does not have.
+    try {
+        {
+            std::ofstream f(join(dir_, "vr_vectors"), std::ios::binary | std::ios::app);
+            if (!f) throw IoError(IoError::Other, "cannot append to vr_vectors of '" + name_ + "'");
+            f.write(reinterpret_cast<const char*>(rows.data()), (std::streamsize)(rows.size() * 4));
+            f.flush();
+            if (!f) throw IoError(IoError::Other, "short write to vr_vectors of '" + name_ + "'");
+        }
+        {
+            std::ofstream f(join(dir_, "vr_payloads"), std::ios::app);
+            if (!f) throw IoError(IoError::Other, "cannot append to vr_payloads of '" + name_ + "'");
+            for (uint64_t i = 0; i < n; ++i) f << (i < payloads.size() ? payloads[i] : std::string()) << "\n";
+            f.flush();
+            if (!f) throw IoError(IoError::Other, "short write to vr_payloads of '" + name_ + "'");
+        }
+        cfg_.count += n;
+        save_config();
+    } catch (...) {
+        // the device holds rows the disk does not: drop the handle (reloaded from disk on next use)
+        cfg_.count = count0;   // save_config throws only while the old vr_config is still in place
+        vrod_index_destroy(index_);
+        index_ = nullptr;
+        trimmed_ = false;
+        payloads_loaded_ = false;
+        payload_cache_.clear();
+        throw;
     }
     if (payloads_loaded_)
         for (uint64_t i = 0; i < n; ++i) payload_cache_.push_back(i < payloads.size() ? payloads[i] : std::string());
-    cfg_.count += n;
-    save_config();
 }
 
 void Collection::search(const std::vector<float>& queries, uint32_t nq, uint32_t k, std::vector<uint64_t>& ids,

@@ -55,6 +55,7 @@ public:
     void set_config(const CollectionConfig& c) { cfg_ = c; }
 
     void save_config() const;
+    void trim_to_count();   // drop rows / payload lines beyond `count` (leftovers of an uncommitted insert)
     void load_config();
     // append rows (n x dim fp32) + payloads to disk and, if resident, to the device index
     void insert(const std::vector<float>& rows, uint32_t dim, const std::vector<std::string>& payloads);
@@ -70,6 +71,7 @@ private:
     vrod_index* index_ = nullptr;
     std::vector<std::string> payload_cache_;
     bool payloads_loaded_ = false;
+    bool trimmed_ = false;
 };
 
 class Database {
