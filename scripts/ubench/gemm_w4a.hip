@@ -1,0 +1,326 @@
+// Prototype (dev tool, not part of the library): successor candidate of the 4-wave 256x256 bf16 tile.
+// Waves are laid out 4 x 1: wave w owns corpus rows [64w, 64w+64) of the tile against ALL 256 queries.
+//   * A (corpus) never touches LDS: each wave streams its own 64 rows global -> VGPR (fragment-shaped
+//     16 rows x 64 B loads, a ring of 4 K-tiles = 128 VGPRs, three K-tiles ahead of the MFMAs);
+//   * B (queries) goes through LDS-DMA into FOUR 32-KB stages (three K-tiles ahead), read by all four
+//     waves; ONE barrier per K-tile, placed in front of the last n-tile's MFMAs so that the first
+//     fragment reads of the next K-tile are covered.
+// Per K-tile the CU's LDS takes 32 KB of fills (was 64) and 128 KB of fragment reads (as before).
+// Epilogue: running max per (lane, query column) -- stands in for the threshold filter.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_w4a gemm_w4a.hip && ./gemm_w4a [rows] [variant]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <type_traits>
+#include <utility>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GLDS16(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+#define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+constexpr int kStageB = 32768;   // one K-tile of the 256 queries
+constexpr int kStages = 4;
+
+struct Args {
+    const char* corpus;   // [rows][ld] bf16
+    const char* queries;  // [1024][ld] bf16
+    float* out;           // [grid][256 threads][16] running maxima
+    uint32_t ld_bytes;
+    uint32_t ntiles;      // 256-row tiles
+    uint32_t nqb;
+    uint32_t flags;
+    unsigned long long* clk;
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// accumulator tile (m, n), m in 0..3 (16 rows), n in 0..15 (16 queries): a[(m*16+n)*4 .. +3]
+template <int BASE, bool ZERO>
+__device__ __forceinline__ void mfma1(const bf16x8& x, const bf16x8& y) {
+    if constexpr (ZERO)
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(x), "v"(y), "i"(BASE), "i"(BASE + 3) : "memory");
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(x), "v"(y), "i"(BASE), "i"(BASE + 3) : "memory");
+}
+template <int BASE>
+__device__ __forceinline__ f32x4 read_acc() {
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
+    return v;
+}
+// one A fragment: 16 rows x 64 B (lane l: row l & 15, bytes [16 (l >> 4), +16) of the half line), straight to VGPRs.
+// The compiler does not count this load: its data is valid only behind the counted vmcnt wait that names the register.
+// a pointer hipcc can keep in an SGPR pair ("s" operands must be provably wave-uniform)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+template <int OFF>
+__device__ __forceinline__ void load_a(bf16x8& dst, uint32_t voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
+}
+
+
+// VAR bit 0: no epilogue (timing only); bit 1: no A loads in the loop (timing only); bit 2: no B DMA in the loop (timing only)
+template <int VAR>
+__global__ __launch_bounds__(256) void gemm_w4a(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t slots = gridDim.x >> 3;
+    const uint32_t spx = slots / a.nqb;           // strips per XCD
+    const uint32_t qb = slot % a.nqb, strip = xcd * spx + slot / a.nqb, nstrips = 8 * spx;
+    if (slot >= spx * a.nqb) return;
+    const uint32_t t0 = (uint32_t)((uint64_t)a.ntiles * strip / nstrips);
+    const uint32_t t1 = (uint32_t)((uint64_t)a.ntiles * (strip + 1) / nstrips);
+    if (t0 >= t1) return;
+
+    const uint32_t KT = a.ld_bytes >> 7;
+    const uint32_t fr = lane & 15, fg = lane >> 4, r7 = fr & 7;
+    // B: LDS-DMA piece p = query rows [8p, 8p+8) x 128 B; lane -> row lane >> 3, 16-B chunk (lane & 7) ^ row
+    const uint32_t st_row = lane >> 3;
+    const uint32_t st_lane_off = st_row * a.ld_bytes + (((lane & 7) ^ st_row) << 4);
+    const uint32_t b_frag0 = ((fr >> 3) << 10) + (r7 << 7);
+    const uint32_t c_off0 = ((0 * 4 + fg) ^ r7) << 4, c_off1 = ((1 * 4 + fg) ^ r7) << 4;
+    const uint64_t piece_stride = 8ull * a.ld_bytes;
+    const char* ub_src = a.queries + (uint64_t)qb * 256 * a.ld_bytes + st_lane_off + (uint64_t)wave * 8 * piece_stride;
+    // A: fragment (m, kk) of the wave's 64 rows = rows [16m, 16m+16) x bytes [64 kk, 64 kk + 64) of the K-tile's line
+    uint32_t voff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        voff[m] = (m * 16 + fr) * a.ld_bytes + fg * 16;
+        // TIMING ONLY (wrong products): the same bytes with adjacent lanes on adjacent 16-B chunks of one row
+        if constexpr (VAR & 8) voff[m] = (m * 16 + (lane >> 2)) * a.ld_bytes + (lane & 3) * 16;
+    }
+    const char* sa = uniform_ptr(a.corpus + ((uint64_t)t0 * 256 + (uint32_t)wave * 64) * a.ld_bytes);   // uniform: K-tile being loaded
+    uint32_t st_kt = 0, st_tile = t0;
+    const uint32_t total_it = (t1 - t0) * KT;
+
+    float best[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) best[n] = -3.0e38f;
+    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+
+    uint32_t ba[4][2];      // LDS byte address of this lane's B fragment chunk: stage, kk
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        ba[st][0] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + st * kStageB + b_frag0 + c_off0;
+        ba[st][1] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + st * kStageB + b_frag0 + c_off1;
+    }
+    bf16x8 RA[4][4][2];     // ring slot, m, kk
+    bf16x8 FB[2][2];        // double buffer, kk
+
+    auto advance = [&]() {   // next K-tile of the strip (clamped at its end: the last K-tile is fetched again, never used)
+        const bool in_tile = st_kt + 1 < KT;
+        const bool next_tile = !in_tile && st_tile + 1 < t1;
+        // VAR bit 4, TIMING ONLY: every tile of the strip reads the strip's first tile (L2-resident)
+        const int64_t da = in_tile ? 128 : next_tile ? ((VAR & 16) ? 0 : (int64_t)256 * a.ld_bytes) - (int64_t)(KT - 1) * 128 : 0;
+        const int64_t db = in_tile ? 128 : next_tile ? -(int64_t)(KT - 1) * 128 : 0;
+        st_kt = in_tile ? st_kt + 1 : next_tile ? 0u : st_kt;
+        st_tile += next_tile ? 1u : 0u;
+        sa = uniform_ptr(sa + da);
+        ub_src += db;
+    };
+
+#define LOADA(S, J) load_a<((J) & 1) * 64>(RA[S][(J) >> 1][(J) & 1], voff[(J) >> 1], sa);
+#define DMAB(S, I) GLDS16(ub_src + (uint64_t)(I) * piece_stride, lds + (S) * kStageB + (wave * 8 + (I)) * 1024);
+// B fragments of n-tile N from stage ST: asm reads, counted by hand (the compiler's own waits before the MFMA
+// statements were lgkmcnt(0): each step then exposed the latency of the reads just issued for the NEXT step)
+#define READB(BUF, ST, N)                                                                           \
+    asm volatile("ds_read_b128 %0, %2 offset:%c4\n\tds_read_b128 %1, %3 offset:%c4"                  \
+                 : "=v"(FB[BUF][0]), "=v"(FB[BUF][1]) : "v"(ba[ST][0]), "v"(ba[ST][1]), "i"((N) * 2048) : "memory");
+// the two reads issued last may stay in flight; everything older (fragments BUF) is back
+#define WAITB(BUF) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(FB[BUF][0]), "+v"(FB[BUF][1]) :: "memory");
+// the 8 MFMAs of n-tile N: (kk, m) order, the same accumulator comes back after 4 instructions
+#define MFMAS(S, BUF, N, ZERO)                                                                      \
+    static_for<0, 8>([&](auto ic) {                                                                 \
+        constexpr int kk = decltype(ic)::value / 4, m = decltype(ic)::value % 4;                    \
+        mfma1<(m * 16 + (N)) * 4, ZERO && kk == 0>(RA[S][m][kk], FB[BUF][kk]);                      \
+    });
+
+    // ---- prologue: K-tiles 0, 1, 2 requested and landed
+#define PROLOGUE_STAGE(S)                                                                           \
+    LOADA(S, 0) LOADA(S, 1) LOADA(S, 2) LOADA(S, 3) LOADA(S, 4) LOADA(S, 5) LOADA(S, 6) LOADA(S, 7)  \
+    DMAB(S, 0) DMAB(S, 1) DMAB(S, 2) DMAB(S, 3) DMAB(S, 4) DMAB(S, 5) DMAB(S, 6) DMAB(S, 7)          \
+    advance();
+    PROLOGUE_STAGE(0) PROLOGUE_STAGE(1) PROLOGUE_STAGE(2)
+#define RA8(S) "+v"(RA[S][0][0]), "+v"(RA[S][0][1]), "+v"(RA[S][1][0]), "+v"(RA[S][1][1]), "+v"(RA[S][2][0]), "+v"(RA[S][2][1]), "+v"(RA[S][3][0]), "+v"(RA[S][3][1])
+    asm volatile("s_waitcnt vmcnt(0)" : RA8(0));
+    asm volatile("" : RA8(1));
+    asm volatile("" : RA8(2));
+    __syncthreads();
+    READB(0, 0, 0)
+
+    // One K-tile with ring slot / LDS stage S (= it & 3); S3 = (S + 3) & 3 is the slot being refilled, S1 = (S + 1) & 3 the next one.
+    // Step n: request B fragments of n+1, 8 MFMAs of n, one memory request (even n: A fragment n/2, odd n: DMA piece n/2)
+#define STEP(S, S3, N, ZERO)                                                                        \
+    READB(((N) + 1) & 1, S, (N) + 1)                                                                \
+    WAITB((N) & 1)                                                                                  \
+    MFMAS(S, (N) & 1, N, ZERO)                                                                      \
+    if constexpr (((N) & 1) == 0) { if constexpr (!(VAR & 2)) { LOADA(S3, (N) >> 1) } }             \
+    else { if constexpr (!(VAR & 4)) { DMAB(S3, (N) >> 1) } }
+#define KTILE_Z(S, S1, S3, ZERO)                                                                    \
+    STEP(S, S3, 0, ZERO) STEP(S, S3, 1, ZERO) STEP(S, S3, 2, ZERO) STEP(S, S3, 3, ZERO)              \
+    STEP(S, S3, 4, ZERO) STEP(S, S3, 5, ZERO) STEP(S, S3, 6, ZERO) STEP(S, S3, 7, ZERO)              \
+    STEP(S, S3, 8, ZERO) STEP(S, S3, 9, ZERO) STEP(S, S3, 10, ZERO) STEP(S, S3, 11, ZERO)            \
+    STEP(S, S3, 12, ZERO) STEP(S, S3, 13, ZERO)                                                     \
+    /* n = 14: its MFMAs, then the last two requests of the K-tile */                               \
+    READB(1, S, 15)                                                                                 \
+    WAITB(0)                                                                                        \
+    MFMAS(S, 0, 14, ZERO)                                                                           \
+    if constexpr (!(VAR & 2)) { LOADA(S3, 7) }                                                      \
+    if constexpr (!(VAR & 4)) { DMAB(S3, 7) }                                                       \
+    /* everything requested two K-tiles ago has landed (this wave's share of K-tile it+1: its A    \
+       fragments and its 8 B pieces); every fragment read of this stage is back; then the barrier \
+       publishes stage S1 and frees stage S for the requests of the next K-tile */                  \
+    asm volatile("s_waitcnt vmcnt(%c10) lgkmcnt(0)" : RA8(S1), "+v"(FB[1][0]), "+v"(FB[1][1]) : "i"((VAR & 6) == 6 ? 0 : (VAR & 6) ? 16 : 32) : "memory"); \
+    BARRIER();                                                                                      \
+    READB(0, S1, 0)                                                                                 \
+    MFMAS(S, 1, 15, ZERO)
+#define KTILE(S, S1, S3)                                                                            \
+    {                                                                                               \
+        if (kt == 0) { KTILE_Z(S, S1, S3, true) } else { KTILE_Z(S, S1, S3, false) }                 \
+        advance();                                                                                  \
+        if (++kt == KT) {                                                                           \
+            kt = 0;                                                                                 \
+            if constexpr (!(VAR & 1)) {                                                             \
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                  \
+                static_for<0, 64>([&](auto ic) {                                                    \
+                    constexpr int m = decltype(ic)::value / 16, n = decltype(ic)::value % 16;       \
+                    const f32x4 v = read_acc<(m * 16 + n) * 4>();                                   \
+                    best[n] = fmaxf(best[n], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));         \
+                });                                                                                 \
+            }                                                                                       \
+        }                                                                                           \
+        if (++it >= total_it) break;                                                                \
+    }
+
+    uint32_t it = 0, kt = 0;
+    for (;;) {
+        KTILE(0, 1, 3)
+        KTILE(1, 2, 0)
+        KTILE(2, 3, 1)
+        KTILE(3, 0, 2)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64() - clk0; a.clk[1] = wall_clock64() - wall0; }
+    if (tid == 0) { a.clk[2 + 2 * blockIdx.x] = wall0; a.clk[3 + 2 * blockIdx.x] = wall_clock64(); }
+    float* o = a.out + ((uint64_t)blockIdx.x * 256 + tid) * 16;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) o[n] = best[n];
+}
+
+__global__ void fill_kernel(uint16_t* p, uint64_t n, uint64_t seed) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t z = (i + seed * 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        const float v = ((int)(z & 0xFFFF) - 32768) * (0.06f / 32768.f);
+        p[i] = (uint16_t)(__float_as_uint(v) >> 16);
+    }
+}
+
+__global__ void ref_kernel(const uint16_t* c, const uint16_t* q, uint32_t rows, uint32_t ld, uint32_t dim, const uint32_t* qsel, float* out) {
+    const uint32_t qi = qsel[blockIdx.y];
+    float best = -3.0e38f;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (uint32_t k = 0; k < dim; ++k)
+            s += __uint_as_float((uint32_t)c[(uint64_t)r * ld + k] << 16) * __uint_as_float((uint32_t)q[(uint64_t)qi * ld + k] << 16);
+        best = fmaxf(best, s);
+    }
+    atomicMax((int*)&out[blockIdx.y], __float_as_int(best < 0.f ? 0.f : best));
+}
+
+constexpr int kLds = kStages * kStageB;
+template <int VAR> static double run(const Args& a, int reps) {
+    hipFuncSetAttribute((const void*)gemm_w4a<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    gemm_w4a<VAR><<<256, 256, kLds>>>(a);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) gemm_w4a<VAR><<<256, 256, kLds>>>(a);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) printf("HIP error: %s\n", hipGetErrorString(e));
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t rows = argc > 1 ? atoi(argv[1]) : 1048576, dim = argc > 4 ? atoi(argv[4]) : 768, ld = (dim + 63) / 64 * 64, nq = 1024;
+    const int var = argc > 2 ? atoi(argv[2]) : 0;
+    const int reps = argc > 3 ? atoi(argv[3]) : 5;
+    uint16_t *d_c, *d_q; float* d_out;
+    hipMalloc(&d_c, (size_t)rows * ld * 2); hipMalloc(&d_q, (size_t)nq * ld * 2); hipMalloc(&d_out, 256 * 256 * 16 * 4);
+    fill_kernel<<<4096, 256>>>(d_c, (uint64_t)rows * ld, 1);
+    fill_kernel<<<256, 256>>>(d_q, (uint64_t)nq * ld, 2);
+    hipMemset(d_out, 0, 256 * 256 * 16 * 4);
+    unsigned long long* d_clk; hipMalloc(&d_clk, 16 + 256 * 16);
+    Args a{(const char*)d_c, (const char*)d_q, d_out, ld * 2, rows / 256, nq / 256, 0, d_clk};
+    double ms = 0;
+    switch (var) {
+        case 0: ms = run<0>(a, reps); break;
+        case 1: ms = run<1>(a, reps); break;   // no epilogue (timing only)
+        case 2: ms = run<2>(a, reps); break;   // no A loads in the loop (timing only)
+        case 4: ms = run<4>(a, reps); break;   // no B DMA in the loop (timing only)
+        case 6: ms = run<6>(a, reps); break;   // neither
+        case 7: ms = run<7>(a, reps); break;   // neither, no epilogue
+        case 8: ms = run<8>(a, reps); break;   // quad-coalesced A loads (timing only)
+        case 16: ms = run<16>(a, reps); break; // A from an L2-resident tile (timing only)
+        case 24: ms = run<24>(a, reps); break; // both
+        default: printf("bad variant\n"); return 1;
+    }
+    const double tf = 2.0 * rows * nq * ld / (ms * 1e-3) / 1e12;
+    unsigned long long hclk[2 + 512]; hipMemcpy(hclk, d_clk, 16 + 256 * 16, hipMemcpyDeviceToHost);
+    {
+        unsigned long long t0 = ~0ull, t1 = 0; double sum = 0, mx = 0, mn = 1e30;
+        for (int b = 0; b < 256; ++b) { if (hclk[2 + 2 * b] < t0) t0 = hclk[2 + 2 * b]; if (hclk[3 + 2 * b] > t1) t1 = hclk[3 + 2 * b]; }
+        for (int b = 0; b < 256; ++b) { const double d = (double)(hclk[3 + 2 * b] - hclk[2 + 2 * b]) * 0.01; sum += d; if (d > mx) mx = d; if (d < mn) mn = d; }
+        printf("  work-group busy time us: min %.1f mean %.1f max %.1f; kernel span %.1f\n", mn, sum / 256, mx, (double)(t1 - t0) * 0.01);
+    }
+    const double ghz = (double)hclk[0] / (double)hclk[1] * 0.1;
+    printf("w4a variant %2d rows %u dim %u: %.3f ms  %7.1f TFLOP/s  sclk %.2f GHz  -> %.1f %% of the MFMA rate at that clock\n", var, rows, dim, ms, tf, ghz,
+           100.0 * tf / (2500.0 * ghz / 2.4));
+    if (var) return 0;
+
+    std::vector<float> h(256 * 256 * 16);
+    hipMemcpy(h.data(), d_out, h.size() * 4, hipMemcpyDeviceToHost);
+    std::vector<float> qmax(nq, -3.0e38f);
+    for (uint32_t b = 0; b < 256; ++b) {
+        const uint32_t slot = b >> 3, qb = slot % 4;
+        for (uint32_t t = 0; t < 256; ++t) {
+            const uint32_t fr = t & 15;
+            for (int n = 0; n < 16; ++n) {
+                const uint32_t q = qb * 256 + n * 16 + fr;
+                qmax[q] = fmaxf(qmax[q], h[((size_t)b * 256 + t) * 16 + n]);
+            }
+        }
+    }
+    uint32_t hsel[16]; for (int i = 0; i < 16; ++i) hsel[i] = (i * 67 + 5) % nq;
+    uint32_t* d_sel; float* d_ref; hipMalloc(&d_sel, 64); hipMalloc(&d_ref, 64);
+    hipMemcpy(d_sel, hsel, 64, hipMemcpyHostToDevice); hipMemset(d_ref, 0, 64);
+    ref_kernel<<<dim3(512, 16), 256>>>(d_c, d_q, rows, ld, dim, d_sel, d_ref);
+    float href[16]; hipMemcpy(href, d_ref, 64, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 16; ++i) {
+        const float g = qmax[hsel[i]];
+        if (fabsf(g - href[i]) > 1e-4f * fmaxf(1.f, fabsf(href[i]))) { ++bad; printf("  q%u: got %g ref %g\n", hsel[i], g, href[i]); }
+    }
+    printf("validation: %s\n", bad ? "MISMATCH" : "ok");
+    return bad ? 2 : 0;
+}

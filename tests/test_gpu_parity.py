@@ -125,12 +125,16 @@ def test_f32_cosine_batched_mfma_large_k(va, oracle):
 def test_duplicates_tie_break_by_id(va, oracle, path):
     rng = np.random.default_rng(5)
     base = rng.standard_normal((50, 64)).astype(np.float32)
-    raw = np.concatenate([base] * 40)  # every row 40 times: massive exact ties
+    raw = np.concatenate([base] * 60)  # every row 60 times: massive exact ties
     rq = base[:3] + 0.01 * rng.standard_normal((3, 64)).astype(np.float32)
     st = run_case(va, oracle, raw, rq, 25, "f32", "cosine", path)
-    # every query sits next to a base row that exists 40 times: rank 25 falls inside that group of
-    # exact ties, no certificate can separate s_k from the left-out copies -> the exact path ran
-    assert st["fallback_queries"] >= 1
+    # every query sits next to a base row that exists 60 times -- more than the k' = 41 candidates the
+    # fast pass keeps: the group of exact ties straddles the candidate cut, T equals s_k, no certificate
+    # can separate the kept copies from the left-out ones -> all three queries took the exact path
+    assert st["fallback_queries"] == 3
+    # 40 copies fit inside k': the certificate holds (ties among candidates are ordered by id) -> no fallback
+    st = run_case(va, oracle, np.concatenate([base] * 40), rq, 25, "f32", "cosine", path)
+    assert st["fallback_queries"] == 0
 
 
 @pytest.mark.parametrize("path", [1, 2])

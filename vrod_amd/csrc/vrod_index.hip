@@ -14,6 +14,8 @@
 // There is no CPU fallback anywhere: without a gfx950 device every entry point fails.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen'ed when a multi-device handle is created
 
 #include <algorithm>
@@ -1055,7 +1057,17 @@ static int composite_open_exchange(vrod_index* idx) {
         std::vector<int> devs;
         for (auto& G : idx->groups) devs.push_back(G.device);
         std::vector<ncclComm_t> comms(devs.size(), nullptr);
-        NCCL_TRY(api.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        // RCCL prints a version banner on stdout at the first communicator of a process, and the host's
+        // stdout is the command's result channel (SEARCHSIMILAR prints its hits there): stdout points at
+        // /dev/null while the communicator is built (callers are single-threaded by contract)
+        fflush(stdout);
+        const int saved = dup(1), nul = open("/dev/null", O_WRONLY);
+        if (saved >= 0 && nul >= 0) (void)dup2(nul, 1);
+        const ncclResult_t ir = api.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+        fflush(stdout);
+        if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
+        if (nul >= 0) close(nul);
+        if (ir != ncclSuccess) return fail(VROD_ERR_HIP, "ncclCommInitAll over %zu devices failed: %s", devs.size(), api.GetErrorString(ir));
         for (size_t u = 0; u < devs.size(); ++u) idx->groups[u].comm = comms[u];
     }
     return VROD_OK;
