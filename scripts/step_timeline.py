@@ -1,11 +1,23 @@
-"""Print the kernel timeline of the last search step in a rocprofv3 kernel_trace.csv."""
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'final_topk' in r['Kernel_Name']]
-j = idx[-1]; k = idx[-2]
-seg = rows[k + 1:j + 1]
-t0 = int(seg[0]['Start_Timestamp'])
-for r in seg:
-    s = int(r['Start_Timestamp']) - t0; e = int(r['End_Timestamp']) - t0
-    print(f"{s/1e3:9.1f} {e/1e3:9.1f} dur={(e-s)/1e3:9.1f} us  {r['Kernel_Name'][:64]}")
+"""Timeline of the last batch of a run under `rocprofv3 --kernel-trace --output-format csv -d DIR`:
+    python scripts/step_timeline.py DIR [first_kernel_substring]
+prints start / end / duration (us) of every dispatch from the last launch of the batch's first kernel
+(default: prep_queries_kernel) to the end of the trace."""
+import csv
+import glob
+import sys
+
+d = sys.argv[1]
+first = sys.argv[2] if len(sys.argv) > 2 else "prep_queries_kernel"
+rows = []
+for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+idx = [i for i, r in enumerate(rows) if first in r[2]]
+if not idx:
+    sys.exit("no dispatch of " + first)
+# the last COMPLETE batch: from the second-to-last first-kernel to the last one
+a, b = (idx[-2], idx[-1]) if len(idx) > 1 else (idx[-1], len(rows))
+t0 = rows[a][0]
+for s, e, n in rows[a:b]:
+    print(f"{(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f} dur={(e - s) / 1e3:9.1f} us  {n[:90]}")

@@ -339,8 +339,8 @@ int main(int argc, char** argv) {
         case 7: ms = run<7>(a, 5); break;     // neither
         case 9: ms = run<9>(a, 5); break;     // no fragment reads in the loop (timing only)
         case 15: ms = run<15>(a, 5); break;   // MFMA only
-        case 17: ms = run<17>(a, 5); break;   // spread DMA, two barriers per K-tile
-        case 19: ms = run<19>(a, 5); break;   // same without the epilogue (timing only)
+        case 17: ms = run<17>(a, argc > 4 ? atoi(argv[4]) : 5); break;   // spread DMA, two barriers per K-tile
+        case 19: ms = run<19>(a, argc > 4 ? atoi(argv[4]) : 5); break;   // same without the epilogue (timing only)
         case 49: ms = run<49>(a, 5); break;   // 17 with 32x32x16 MFMAs (timing only)
         case 51: ms = run<51>(a, 5); break;   // 19 with 32x32x16 MFMAs (timing only)
         case 47: ms = run<47>(a, 5); break;   // 15 (MFMA only) with 32x32x16 MFMAs

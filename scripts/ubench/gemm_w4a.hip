@@ -230,8 +230,11 @@ __global__ void fill_kernel(uint16_t* p, uint64_t n, uint64_t seed) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t z = (i + seed * 0x9E3779B97F4A7C15ull);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-        const float v = ((int)(z & 0xFFFF) - 32768) * (0.06f / 32768.f);
-        p[i] = (uint16_t)(__float_as_uint(v) >> 16);
+        float v = ((int)(z & 0xFFFF) - 32768) * (0.06f / 32768.f);
+        // seed >= 100: the library's synthetic stream in spirit (sum of four 16-bit fields ~ Gaussian, rows of norm ~1 at d = 768)
+        if (seed >= 100) v = ((float)(z & 0xFFFF) + (float)((z >> 16) & 0xFFFF) + (float)((z >> 32) & 0xFFFF) + (float)(z >> 48) - 131070.f) * (1.0f / (37837.f * 27.7f));
+        uint32_t u = __float_as_uint(v); u += 0x7FFFu + ((u >> 16) & 1u);
+        p[i] = (uint16_t)(u >> 16);
     }
 }
 
@@ -267,8 +270,9 @@ int main(int argc, char** argv) {
     const int reps = argc > 3 ? atoi(argv[3]) : 5;
     uint16_t *d_c, *d_q; float* d_out;
     hipMalloc(&d_c, (size_t)rows * ld * 2); hipMalloc(&d_q, (size_t)nq * ld * 2); hipMalloc(&d_out, 256 * 256 * 16 * 4);
-    fill_kernel<<<4096, 256>>>(d_c, (uint64_t)rows * ld, 1);
-    fill_kernel<<<256, 256>>>(d_q, (uint64_t)nq * ld, 2);
+    const uint64_t seed0 = argc > 5 ? atoi(argv[5]) : 0;   // 100: Gaussian-like unit rows
+    fill_kernel<<<4096, 256>>>(d_c, (uint64_t)rows * ld, seed0 + 1);
+    fill_kernel<<<256, 256>>>(d_q, (uint64_t)nq * ld, seed0 + 2);
     hipMemset(d_out, 0, 256 * 256 * 16 * 4);
     unsigned long long* d_clk; hipMalloc(&d_clk, 16 + 256 * 16);
     Args a{(const char*)d_c, (const char*)d_q, d_out, ld * 2, rows / 256, nq / 256, 0, d_clk};

@@ -27,5 +27,5 @@ def test_w4_kernel_accumulator_file_is_untouched_by_the_compiler(tmp_path):
     finally:
         sys.path.pop(0)
     text = asm.read_text()
-    assert "scan_mfma_w4_kernel" in text, "the 4-wave kernel is not in the build"
+    assert "scan_mfma_w4_kernel" in text and "scan_mfma_w4a_kernel" in text, "the 4-wave kernels are not in the build"
     assert audit_w4.audit(str(asm)) == 0

@@ -701,7 +701,7 @@ __device__ __forceinline__ void flush_log_w4(const MfmaKernelArgs& a, const uint
         }
     }
     __syncthreads();
-    if (tid == 0) { lds_zero3(log_cnt + 3); lds_zero3(log_cnt + 5); }
+    if (tid == 0) { lds_zero3(log_cnt + 2); lds_zero3(log_cnt + 5); }   // [2..3] flush-due flags, [4..7] wave counts
     __syncthreads();
 }
 
@@ -1019,6 +1019,378 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         __syncthreads();
         if constexpr (!DENSE) flush_log_w4(a, log, log_cnt, qb, rel_base, tid);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Schedule 4 (bf16 default, plain rows): 4 waves laid out 4 x 1, the corpus never touches LDS.
+//
+// Wave w owns rows [64 w, 64 w + 64) of the 256-row tile against ALL 256 queries of the block:
+// 4 x 16 MFMA tiles, the same 256 accumulator registers a[0:255] (tile (m, n) = a[(m*16+n)*4 .. +3]).
+//   * A (corpus rows): nothing is shared between waves any more, so the rows go global -> VGPR
+//     as MFMA A fragments (16 rows x 64 B per instruction: lane l holds bytes [16 (l >> 4), +16) of
+//     half line kk of row l & 15 -- the lane -> k mapping of the B fragments, so equal elements meet
+//     whatever the instruction's internal k order), a ring of 4 K-tiles (128 VGPRs) requested three
+//     K-tiles ahead of the MFMAs that use them.  The loads are inline asm: hipcc would wait vmcnt(0)
+//     before every use of an ordinary load while LDS-DMA is in flight; their data is valid behind the
+//     counted wait that names the registers ("+v").
+//   * B (queries): LDS-DMA into FOUR 32-KB stages, three K-tiles ahead, read by all four waves
+//     (asm ds_read_b128 + counted lgkmcnt(2): the compiler's own lgkmcnt(0) in front of every MFMA
+//     group exposed the latency of the reads just issued for the next group).
+//   * ONE barrier per K-tile, placed in front of the last n-tile's MFMAs: the wait in front of it
+//     (vmcnt(32): everything requested two K-tiles ago has landed = this wave's A fragments and B
+//     pieces of K-tile it+1; lgkmcnt(0): its fragment reads of stage it are back) makes the barrier
+//     publish stage it+1 and free stage it for the requests of K-tile it+4; the first fragment reads
+//     of K-tile it+1 then hide behind the last 8 MFMAs of K-tile it.
+// Every wave issues exactly 16 memory requests per K-tile (8 A fragments, 8 DMA pieces; the L2
+// form adds 4 row-norm loads in a tile's first K-tile, which only makes the counted wait stricter).
+// Per K-tile the CU's LDS takes 32 KB of fills (4-wave kernel above: 64 KB) and 128 KB of fragment
+// reads (the same).  Prototype scripts/ubench/gemm_w4a.hip, same box, 4M x 768: 1.29-1.30 PFLOP/s
+// against 1.09 for the structure above (profiles/r02/mfma_experiments.md).
+// ---------------------------------------------------------------------------------------------
+constexpr int kW4aStageB = 32768;                          // one K-tile of the block's 256 queries
+constexpr int kW4aLog = 4 * kW4aStageB;                    // the wave-private log segments behind the four stages
+constexpr int kW4aCtl = kW4aLog + kLogCap * 8;
+constexpr int kW4aThr = kW4aCtl + 64;                      // [256] f32 thresholds
+constexpr int kW4aQn2 = kW4aThr + 1024;                    // [256] f32 query norms (L2)
+constexpr int kW4aXn2 = kW4aQn2 + 1024;                    // [2][256] f32 row norms (L2), slot = tile parity
+constexpr int kLdsTotalW4a = kW4aXn2 + 2048;
+
+// a pointer hipcc keeps in an SGPR pair ("s" asm operands must be provably wave-uniform)
+__device__ __forceinline__ const char* w4a_uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+// The A ring lives in v[128:255], named literally like the accumulators (slot s, fragment j = m*2+kk ->
+// v[128 + (s*8+j)*4 .. +3]): an asm load's data is in flight until the counted vmcnt wait, and registers hipcc
+// allocates may be copied, split or re-assigned in between (with the ring in "=v" operands it did exactly that
+// under the epilogue's register pressure).  The kernel is compiled with amdgpu_num_vgpr(128): hipcc keeps to
+// v0..v127, the clobber list of the kernel's first statement makes the descriptor allocate all 256 + 256
+// registers, and scripts/audit_w4.py checks that no compiler instruction names v128 or above.
+template <int DST, int OFF>
+__device__ __forceinline__ void w4a_load_a(uint32_t voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 v[%c2:%c3], %0, %1 offset:%c4" :: "v"(voff), "s"(sbase), "i"(DST), "i"(DST + 3), "i"(OFF) : "memory");
+}
+template <int ACC, int RA, bool ZERO>
+__device__ __forceinline__ void w4a_mfma1(const bf16x8& y) {
+    if constexpr (ZERO)
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c1:%c2], v[%c3:%c4], %0, 0" ::"v"(y), "i"(ACC), "i"(ACC + 3), "i"(RA), "i"(RA + 3) : "memory");
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c1:%c2], v[%c3:%c4], %0, a[%c1:%c2]" ::"v"(y), "i"(ACC), "i"(ACC + 3), "i"(RA), "i"(RA + 3) : "memory");
+}
+constexpr int kW4aRing = 128;   // first VGPR of the A ring
+// one LDS-DMA piece (1 KB: 64 lanes x 16 B) from sbase + voff into the wave-uniform LDS byte address lds_dst.
+// In asm, with M0 saved and restored inside the statement: the builtin form keeps a 64-bit per-lane pointer
+// per piece (16 VGPRs the 4 x 1 kernel does not have), and hipcc's waits stay out of the way.
+__device__ __forceinline__ void w4a_dma_piece(uint32_t lds_dst, uint32_t voff, const char* sbase) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+// The fused filter of the 4 x 1 layout: the wave's 64 x 256 scores (a[0:255]) against the lane's 16
+// thresholds.  row_w = first row of the lane's 4-row group in tile m = 0; xn_l = its row norms in LDS (L2), 16 floats apart per m.
+template <int METRIC>
+__device__ __forceinline__ void w4a_filter_tile(const MfmaKernelArgs& a, const float* thr_l, const float* qn2_l, const float* xn_l,
+                                                uint32_t row_w, uint32_t fr, uint32_t qb, uint32_t rel_base,
+                                                uint2* log /* this wave's segment */, uint32_t* log_cnt, int wave, uint32_t& wlog,
+                                                uint32_t flag_word /* log_cnt word that asks for a flush: 2 + tile parity */) {
+    const uint32_t wlog_in = wlog;
+    const uint32_t lds_log_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log;
+    // Everything the epilogue derives from the lane's column / row is computed HERE, once per tile: left visible,
+    // hipcc hoists it out of the scan loop (16 list pointers, 16 shifted column ids, 16 LDS addresses ... ~70
+    // loop-invariant VGPRs) and then parks what no longer fits in the accumulator file (scripts/audit_w4.py).
+    asm volatile("" : "+v"(fr), "+v"(row_w));
+    // the last MFMAs are still in the pipe: an accumulator may be read 4 passes + 2 states later
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    // groups of NG n-tiles: NG thresholds (+ NG query norms) + NG running bests live at a time -- hipcc has
+    // 128 VGPRs here (the A ring owns the other 128)
+    constexpr int NG = METRIC == M_L2 ? 4 : 8;
+    static_for<0, 16 / NG>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        float thr[NG], qn2[NG], best[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            thr[j] = thr_l[fr + (h * NG + j) * 16];
+            qn2[j] = METRIC == M_L2 ? qn2_l[fr + (h * NG + j) * 16] : 0.0f;
+            best[j] = worst_score(METRIC);
+        }
+        static_for<0, 4>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (METRIC == M_L2) xv = *reinterpret_cast<const f32x4*>(xn_l + m * 16);
+            static_for<0, NG>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const f32x4 v = w4_read_acc<(m * 16 + h * NG + j) * 4>();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2[j]);
+                    best[j] = METRIC == M_COSINE ? __builtin_fmaxf(best[j], sc) : __builtin_fminf(best[j], sc);
+                }
+            });
+        });
+        uint32_t hitmask = 0u;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) hitmask |= better<METRIC>(best[j], thr[j]) ? (1u << j) : 0u;
+        if (__any(hitmask != 0u)) {
+            static_for<0, NG>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (!__any((hitmask >> j) & 1u)) return;
+                const uint32_t ql = fr + (h * NG + j) * 16;
+                static_for<0, 4>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    const f32x4 v = w4_read_acc<(m * 16 + h * NG + j) * 4>();
+                    f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (METRIC == M_L2) xv = *reinterpret_cast<const f32x4*>(xn_l + m * 16);
+                    float sc[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[r] = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2[j]);
+                    const float tb = METRIC == M_COSINE ? __builtin_fmaxf(__builtin_fmaxf(sc[0], sc[1]), __builtin_fmaxf(sc[2], sc[3]))
+                                                        : __builtin_fminf(__builtin_fminf(sc[0], sc[1]), __builtin_fminf(sc[2], sc[3]));
+                    if (!__any(better<METRIC>(tb, thr[j]))) return;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t row = row_w + m * 16 + r;
+                        const bool hitr = better<METRIC>(sc[r], thr[j]) && row >= a.row_lo && row < a.row_end;
+                        // the wave owns a quarter of the log and counts its entries in a register: a ballot and
+                        // a lane prefix give every hit its slot (see w4_filter_tile)
+                        const unsigned long long hm = __ballot(hitr);
+                        if (hm == 0ull) continue;
+                        const uint32_t pos = wlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                        if (hitr) {
+                            if (pos < (uint32_t)kLogCapW4) {
+                                const uint64_t e = ((uint64_t)((ql << 24) | (row - rel_base)) << 32) | __float_as_uint(sc[r]);
+                                asm volatile("ds_write_b64 %0, %1" :: "v"(lds_log_addr + pos * 8u), "v"(e) : "memory");
+                            } else {
+                                global_append(a, qb * kBN + ql, __float_as_uint(sc[r]), row);
+                            }
+                        }
+                        wlog += (uint32_t)__builtin_popcountll(hm);
+                    }
+                });
+            });
+        }
+    });
+    if (wlog != wlog_in) {
+        const uint32_t cnt_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log_cnt;
+        asm volatile("ds_write_b32 %0, %1" :: "v"(cnt_addr + 16u + 4u * (uint32_t)wave), "v"(wlog) : "memory");
+        if (wlog >= (uint32_t)(kLogCapW4 / 2)) asm volatile("ds_write_b32 %0, %1" :: "v"(cnt_addr + 4u * flag_word), "v"(1u) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int METRIC>
+__device__ __forceinline__ void w4a_dense_store_tile(const MfmaKernelArgs& a, const float* qn2_l, const float* xn_l, uint32_t fr,
+                                                     uint32_t row_w, uint32_t gq0) {
+    asm volatile("" : "+v"(fr), "+v"(row_w), "+v"(gq0));   // computed per tile, not hoisted (see w4a_filter_tile)
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    static_for<0, 16>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        const float qn2 = METRIC == M_L2 ? qn2_l[fr + n * 16] : 0.0f;
+        float* out = a.dense_out + (uint64_t)(gq0 + n * 16) * a.dense_ld;
+        static_for<0, 4>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const uint32_t row = row_w + m * 16;
+            const f32x4 v = w4_read_acc<(m * 16 + n) * 4>();
+            f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (METRIC == M_L2) xv = *reinterpret_cast<const f32x4*>(xn_l + m * 16);
+            f32x4 sc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2);
+            if (row - a.row_lo < a.dense_ld) *reinterpret_cast<f32x4*>(out + (row - a.row_lo)) = sc;
+        });
+    });
+}
+
+template <int METRIC, bool DENSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void scan_mfma_w4a_kernel(const MfmaKernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // makes the kernel descriptor allocate a[0:255] (accumulators) and v[128:255] (A ring)
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+    uint32_t* log_cnt = reinterpret_cast<uint32_t*>(lds + kW4aCtl);  // [3] flush due, [4..7] wave counts
+    uint2* log = reinterpret_cast<uint2*>(lds + kW4aLog);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t strip, qb0, qb_step;
+    if (!wg_assignment(a, strip, qb0, qb_step)) return;
+    const uint32_t t0 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * strip / a.nstrips);
+    const uint32_t t1 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * (strip + 1) / a.nstrips);
+    if (t0 >= t1) return;
+
+    if (tid == 0) { lds_zero3(log_cnt); lds_zero3(log_cnt + 3); lds_zero3(log_cnt + 5); }
+
+    const uint32_t ld_bytes = a.ld_bytes;
+    const uint32_t KT = ld_bytes >> 7;
+    const uint32_t rel_base = a.tile_first * kBM;
+    const uint32_t fr = lane & 15, fg = lane >> 4, r7 = fr & 7;
+    const uint32_t total_it = (t1 - t0) * KT;
+    const uint32_t qb = a.qb_base + qb0;   // ONE query block per work-group (see scan_mfma_w4_kernel)
+    float* thr_l = reinterpret_cast<float*>(lds + kW4aThr);
+    float* qn2_l = reinterpret_cast<float*>(lds + kW4aQn2);
+    thr_l[tid] = DENSE ? 0.0f : a.thr[qb * kBN + tid];
+    qn2_l[tid] = METRIC == M_L2 ? a.qnorm2[qb * kBN + tid] : 0.0f;
+    // (published by the prologue's __syncthreads)
+
+    // B: LDS-DMA piece p = query rows [8p, 8p+8) x one 128-B line; lane -> row lane >> 3, 16-B chunk (lane & 7) ^ row;
+    // this wave moves pieces 8 wave .. 8 wave + 7 of every K-tile
+    const uint32_t st_row = lane >> 3;
+    const uint32_t st_lane_off = st_row * ld_bytes + (((lane & 7) ^ st_row) << 4);
+    const uint32_t piece_stride = 8u * ld_bytes;   // piece i of this wave: 8 i rows further (added to the scalar base)
+    const char* sb = w4a_uniform_ptr(a.queries + ((uint64_t)qb * kBN + (uint32_t)wave * 64) * ld_bytes);   // K-tile being requested
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t dma_dst0 = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)wave * 8192u);   // + stage * 32768 + piece * 1024
+    // B fragment of n-tile n, half kk: row n*16 + fr of the stage, chunk (kk*4 + fg) ^ (row & 7).  Two address pairs:
+    // stages 0-1 through the 16-bit instruction offset of the first, stages 2-3 of the second
+    uint32_t ba[2][2];
+    {
+        const uint32_t b_frag0 = lds_base + ((fr >> 3) << 10) + (r7 << 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ba[h][0] = b_frag0 + h * 2 * kW4aStageB + (((0 * 4 + fg) ^ r7) << 4);
+            ba[h][1] = b_frag0 + h * 2 * kW4aStageB + (((1 * 4 + fg) ^ r7) << 4);
+        }
+    }
+    // A: fragment (m, kk) of the wave's 64 rows = rows [16m, 16m+16) x bytes [64 kk, +64) of the K-tile's line
+    // (one lane offset; the 16 m rows go to the scalar base)
+    const uint32_t voff = fr * ld_bytes + fg * 16;
+    const uint32_t m_stride = 16u * ld_bytes;
+    const char* sa = w4a_uniform_ptr(a.corpus + ((uint64_t)t0 * kBM + (uint32_t)wave * 64) * ld_bytes);   // K-tile being requested
+    uint32_t st_kt = 0, st_tile = t0;
+    auto advance = [&]() {   // next K-tile of the strip (clamped at its end: the last K-tile is requested again, never used)
+        const bool in_tile = st_kt + 1 < KT;
+        const bool next_tile = !in_tile && st_tile + 1 < t1;
+        const int64_t da = in_tile ? 128 : next_tile ? (int64_t)kBM * ld_bytes - (int64_t)(KT - 1) * 128 : 0;
+        const int64_t db = in_tile ? 128 : next_tile ? -(int64_t)(KT - 1) * 128 : 0;
+        st_kt = in_tile ? st_kt + 1 : next_tile ? 0u : st_kt;
+        st_tile += next_tile ? 1u : 0u;
+        sa = w4a_uniform_ptr(sa + da);
+        sb = w4a_uniform_ptr(sb + db);
+    };
+    // L2: the tile's 256 row norms -> LDS slot of its parity, one DMA piece by wave 0 in the tile's first K-tile
+    const char* xn_base = w4a_uniform_ptr(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)t0 * kBM));
+    const float* xn_lds = reinterpret_cast<const float*>(lds + kW4aXn2);
+
+    bf16x8 FB[2][2];        // double buffer, kk
+
+// A fragment J = m*2 + kk of ring slot S: a[256 + (S*8 + J)*4 .. +3]
+#define W4A_LOADA(S, J) w4a_load_a<kW4aRing + ((S) * 8 + (J)) * 4, ((J) & 1) * 64>(voff, sa + (uint32_t)((J) >> 1) * m_stride);
+#define W4A_DMAB(S, I) w4a_dma_piece(dma_dst0 + (uint32_t)((S) * kW4aStageB + (I) * 1024), st_lane_off, sb + (uint32_t)(I) * piece_stride);
+#define W4A_READB(BUF, ST, N)                                                                       \
+    asm volatile("ds_read_b128 %0, %2 offset:%c4\n\tds_read_b128 %1, %3 offset:%c4"                  \
+                 : "=v"(FB[BUF][0]), "=v"(FB[BUF][1]) : "v"(ba[(ST) >> 1][0]), "v"(ba[(ST) >> 1][1]), "i"(((ST) & 1) * kW4aStageB + (N) * 2048) : "memory");
+// the two reads issued last may stay in flight; everything older (fragments BUF) is back
+#define W4A_WAITB(BUF) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(FB[BUF][0]), "+v"(FB[BUF][1]) :: "memory");
+// the 8 MFMAs of n-tile N in (kk, m) order: an accumulator comes back after 4 instructions
+#define W4A_MFMAS(S, BUF, N, ZERO)                                                                  \
+    static_for<0, 8>([&](auto ic) {                                                                 \
+        constexpr int kk = decltype(ic)::value / 4, m = decltype(ic)::value % 4;                    \
+        w4a_mfma1<(m * 16 + (N)) * 4, kW4aRing + ((S) * 8 + m * 2 + kk) * 4, ZERO && kk == 0>(FB[BUF][kk]); \
+    });
+
+    // ---- prologue: K-tiles 0, 1, 2 requested and landed
+#define W4A_PROLOGUE_STAGE(S)                                                                       \
+    W4A_LOADA(S, 0) W4A_LOADA(S, 1) W4A_LOADA(S, 2) W4A_LOADA(S, 3) W4A_LOADA(S, 4) W4A_LOADA(S, 5) W4A_LOADA(S, 6) W4A_LOADA(S, 7) \
+    W4A_DMAB(S, 0) W4A_DMAB(S, 1) W4A_DMAB(S, 2) W4A_DMAB(S, 3) W4A_DMAB(S, 4) W4A_DMAB(S, 5) W4A_DMAB(S, 6) W4A_DMAB(S, 7) \
+    advance();
+    W4A_PROLOGUE_STAGE(0) W4A_PROLOGUE_STAGE(1) W4A_PROLOGUE_STAGE(2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    W4A_READB(0, 0, 0)
+
+    // Step n of a K-tile in ring slot / stage S (S3 = the slot being refilled): request the B fragments of n+1,
+    // 8 MFMAs of n, one memory request (even n: A fragment n/2, odd n: DMA piece n/2)
+#define W4A_STEP(S, S3, N, ZERO)                                                                    \
+    W4A_READB(((N) + 1) & 1, S, (N) + 1)                                                            \
+    W4A_WAITB((N) & 1)                                                                              \
+    W4A_MFMAS(S, (N) & 1, N, ZERO)                                                                  \
+    if constexpr (((N) & 1) == 0) { W4A_LOADA(S3, (N) >> 1) } else { W4A_DMAB(S3, (N) >> 1) }
+#define W4A_KTILE_Z(S, S1, S3, ZERO)                                                                \
+    W4A_STEP(S, S3, 0, ZERO) W4A_STEP(S, S3, 1, ZERO) W4A_STEP(S, S3, 2, ZERO) W4A_STEP(S, S3, 3, ZERO)          \
+    W4A_STEP(S, S3, 4, ZERO) W4A_STEP(S, S3, 5, ZERO) W4A_STEP(S, S3, 6, ZERO) W4A_STEP(S, S3, 7, ZERO)          \
+    W4A_STEP(S, S3, 8, ZERO) W4A_STEP(S, S3, 9, ZERO) W4A_STEP(S, S3, 10, ZERO) W4A_STEP(S, S3, 11, ZERO)        \
+    W4A_STEP(S, S3, 12, ZERO) W4A_STEP(S, S3, 13, ZERO)                                             \
+    W4A_READB(1, S, 15)                                                                             \
+    W4A_WAITB(0)                                                                                    \
+    W4A_MFMAS(S, 0, 14, ZERO)                                                                       \
+    W4A_LOADA(S3, 7)                                                                                \
+    W4A_DMAB(S3, 7)                                                                                 \
+    asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" : "+v"(FB[1][0]), "+v"(FB[1][1]) :: "memory");     \
+    VROD_BARRIER();                                                                                 \
+    /* a flush is decided here, behind the first barrier that follows a tile's epilogue: every wave's "flush due" \
+       word of that tile (parity-indexed, so the next tile's epilogue cannot race this read) and its count are    \
+       published, and no wave is past this point before all have read it (the flush itself synchronises)          \
+    */                                                                                              \
+    if (!DENSE && flush_word) {                                                                     \
+        if (log_cnt[flush_word] != 0u) {                                                            \
+            flush_log_w4(a, log, log_cnt, qb, rel_base, tid);                                       \
+            wlog = 0u;                                                                              \
+        }                                                                                           \
+        flush_word = 0u;                                                                            \
+    }                                                                                               \
+    W4A_READB(0, S1, 0)                                                                             \
+    W4A_MFMAS(S, 1, 15, ZERO)
+#define W4A_KTILE(S, S1, S3)                                                                        \
+    {                                                                                               \
+        /* pacing of the sibling work-groups of a strip (they share every corpus tile through their XCD's L2): a \
+           relaxed counter barrier every pace_every K-tiles, speed only.  Bounded: a sibling that is not       \
+           resident (co-tenant kernels, counter modes that serialise dispatch) costs ONE short timeout, after  \
+           which this work-group stops pacing for the rest of the launch */                                     \
+        if (a.pace_every && pace_on && it > 0 && (it % a.pace_every) == 0 && tid == 0) {            \
+            uint32_t* ctr = a.pace + strip;                                                         \
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            \
+            const uint32_t want = a.nqb * (it / a.pace_every);                                      \
+            bool ok = false;                                                                        \
+            for (uint32_t spin = 0; spin < 64u; ++spin) {   /* <= ~20 us: 128 cycles of sleep + an L2 round trip per spin */ \
+                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; } \
+                __builtin_amdgcn_s_sleep(2);                                                        \
+            }                                                                                       \
+            pace_on = ok;                                                                           \
+        }                                                                                           \
+        if constexpr (METRIC == M_L2 && !DENSE) {                                                   \
+            if (kt == 0) {                                                                          \
+                if (wave == 0) w4a_dma_piece(__builtin_amdgcn_readfirstlane(lds_base + kW4aXn2 + (tile & 1u) * 1024u), (uint32_t)lane * 16u, xn_base); \
+                xn_base = w4a_uniform_ptr(xn_base + (tile + 1 < t1 ? kBM * 4 : 0));                  \
+            }                                                                                       \
+        }                                                                                           \
+        if (kt == 0) { W4A_KTILE_Z(S, S1, S3, true) } else { W4A_KTILE_Z(S, S1, S3, false) }         \
+        advance();                                                                                  \
+        if (++kt == KT) {                                                                           \
+            kt = 0;                                                                                 \
+            /* fewer than 3 K-tiles per tile: the norms were requested less than two K-tiles ago */ \
+            if (METRIC == M_L2 && !DENSE && KT < 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VROD_BARRIER(); } \
+            if constexpr (DENSE)                                                                    \
+                w4a_dense_store_tile<METRIC>(a, qn2_l, a.xnorm2 + tile * kBM + wave * 64 + fg * 4, fr, tile * kBM + wave * 64 + fg * 4, qb * kBN + fr); \
+            else                                                                                    \
+                w4a_filter_tile<METRIC>(a, thr_l, qn2_l, xn_lds + (tile & 1u) * 256u + wave * 64 + fg * 4, tile * kBM + wave * 64 + fg * 4, fr, qb, rel_base, \
+                                        log + wave * kLogCapW4, log_cnt, wave, wlog, 2u + (tile & 1u)); \
+            flush_word = 2u + (tile & 1u);                                                          \
+            ++tile;                                                                                 \
+        }                                                                                           \
+        if (++it >= total_it) break;                                                                \
+    }
+
+    uint32_t it = 0, kt = 0, tile = t0;
+    uint32_t wlog = 0u;   // entries in this wave's log segment (wave-uniform)
+    bool pace_on = true;
+    uint32_t flush_word = 0u;   // != 0: the log_cnt word to look at behind the next barrier (wave-uniform)
+    for (;;) {
+        W4A_KTILE(0, 1, 3)
+        W4A_KTILE(1, 2, 0)
+        W4A_KTILE(2, 3, 1)
+        W4A_KTILE(3, 0, 2)
+    }
+#undef W4A_LOADA
+#undef W4A_DMAB
+#undef W4A_READB
+#undef W4A_WAITB
+#undef W4A_MFMAS
+#undef W4A_PROLOGUE_STAGE
+#undef W4A_STEP
+#undef W4A_KTILE_Z
+#undef W4A_KTILE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (!DENSE) flush_log_w4(a, log, log_cnt, qb, rel_base, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1362,8 +1734,24 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
         hipExtLaunchKernelGGL((scan_mfma_w4_kernel<MM, DN, SP>), dim3(grid), dim3(256), kLdsTotalW4, s,        \
                               first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr, 0, a);        \
     } while (0)
-#define VROD_MFMA_W4K(MM, DN) do { if (split) VROD_MFMA_W4K_(MM, DN, true); else VROD_MFMA_W4K_(MM, DN, false); } while (0)
+#define VROD_MFMA_W4AK(MM, DN)                                                                              \
+    do {                                                                                                    \
+        static bool attr_set = false;                                                                       \
+        if (!attr_set) {                                                                                    \
+            (void)hipFuncSetAttribute((const void*)scan_mfma_w4a_kernel<MM, DN>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotalW4a);            \
+            attr_set = true;                                                                                \
+        }                                                                                                   \
+        hipExtLaunchKernelGGL((scan_mfma_w4a_kernel<MM, DN>), dim3(grid), dim3(256), kLdsTotalW4a, s,          \
+                              first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr, 0, a);        \
+    } while (0)
+// plain bf16 rows: the 4 x 1 kernel (corpus global -> VGPR); the SPLIT form of the pass keeps the 2 x 2 kernel
+#define VROD_MFMA_W4K(MM, DN) do { if (split) VROD_MFMA_W4K_(MM, DN, true); else if (w4a) VROD_MFMA_W4AK(MM, DN); else VROD_MFMA_W4K_(MM, DN, false); } while (0)
     const bool split = h.a_wrap != 0;
+    // VROD_MFMA_W4A=1: the 4 x 1 kernel (corpus global -> VGPR).  Measured on the same box it ties or loses to the
+    // 2 x 2 kernel by 1-3 % (profiles/r02/mfma_experiments.md): half the LDS fills, but the A fragments cost the
+    // vector-memory path as much as the DMA pieces they replace.  Kept selectable, covered by the same tests.
+    static const bool w4a = [] { const char* e = getenv("VROD_MFMA_W4A"); return e && e[0] == '1'; }();
     if (dtype == DT_BF16 && h.nq > 0 && h.nq <= mfma_skinny_max_queries(split, split ? a.lda_bytes : a.ld_bytes)) {
         // rows in LDS: the K extent of a corpus row ([hi | lo] planes in the split form)
         const uint32_t qrow = split ? a.lda_bytes : a.ld_bytes;
@@ -1415,6 +1803,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
         return;
     }
 #undef VROD_MFMA_W4K
+#undef VROD_MFMA_W4AK
 #undef VROD_MFMA_W4K_
 #define VROD_MFMA_P(TT, MM, GPV, DN)                                                                            \
     do {                                                                                                    \
