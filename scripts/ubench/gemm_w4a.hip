@@ -154,6 +154,23 @@ __global__ __launch_bounds__(256) void gemm_w4a(const Args a) {
         mfma1<(m * 16 + (N)) * 4, ZERO && kk == 0>(RA[S][m][kk], FB[BUF][kk]);                      \
     });
 
+// VAR bit 5 (interleaved epilogue): the tile's last K-tile runs rows m = 0,1 for all n first, then rows m = 2,3 with the
+// epilogue reads of m = 0,1 between their MFMAs; the next tile's first K-tile runs m = 0,1 (C = 0 form) with the
+// epilogue reads of the previous tile's m = 2,3 between them, then m = 2,3.  An accumulator is read >= 64 MFMAs
+// after it was last written.  (KT >= 2 only.)
+#define MFMAS_H(S, BUF, N, ZERO, H)                                                                 \
+    static_for<0, 4>([&](auto ic) {                                                                 \
+        constexpr int kk = decltype(ic)::value / 2, m = 2 * (H) + decltype(ic)::value % 2;          \
+        mfma1<(m * 16 + (N)) * 4, ZERO && kk == 0>(RA[S][m][kk], FB[BUF][kk]);                      \
+    });
+#define EPI_H(N, H)                                                                                 \
+    {                                                                                               \
+        const f32x4 v0 = read_acc<((2 * (H)) * 16 + (N)) * 4>();                                    \
+        const f32x4 v1 = read_acc<((2 * (H) + 1) * 16 + (N)) * 4>();                                \
+        best[N] = fmaxf(best[N], fmaxf(fmaxf(fmaxf(v0[0], v0[1]), fmaxf(v0[2], v0[3])), fmaxf(fmaxf(v1[0], v1[1]), fmaxf(v1[2], v1[3])))); \
+    }
+#define NOEPI(N, H)
+
     // ---- prologue: K-tiles 0, 1, 2 requested and landed
 #define PROLOGUE_STAGE(S)                                                                           \
     LOADA(S, 0) LOADA(S, 1) LOADA(S, 2) LOADA(S, 3) LOADA(S, 4) LOADA(S, 5) LOADA(S, 6) LOADA(S, 7)  \
@@ -193,13 +210,40 @@ __global__ __launch_bounds__(256) void gemm_w4a(const Args a) {
     BARRIER();                                                                                      \
     READB(0, S1, 0)                                                                                 \
     MFMAS(S, 1, 15, ZERO)
+// one step of a two-pass K-tile: fragments of the next step, 4 MFMAs of half H, an epilogue piece, a memory request on even steps
+#define STEP2(S, S3, N, NEXTN, ZERO, H, EPI, EH, REQ)                                               \
+    READB(((N) + 1) & 1, S, NEXTN)                                                                  \
+    WAITB((N) & 1)                                                                                  \
+    MFMAS_H(S, (N) & 1, N, ZERO, H)                                                                 \
+    EPI(N, EH)                                                                                      \
+    REQ
+#define PASS2(S, S3, ZERO, H, EPI, EH, R0, R1, R2, R3, R4, R5, R6, R7)                               \
+    STEP2(S, S3, 0, 1, ZERO, H, EPI, EH, R0) STEP2(S, S3, 1, 2, ZERO, H, EPI, EH, ) STEP2(S, S3, 2, 3, ZERO, H, EPI, EH, R1) STEP2(S, S3, 3, 4, ZERO, H, EPI, EH, ) \
+    STEP2(S, S3, 4, 5, ZERO, H, EPI, EH, R2) STEP2(S, S3, 5, 6, ZERO, H, EPI, EH, ) STEP2(S, S3, 6, 7, ZERO, H, EPI, EH, R3) STEP2(S, S3, 7, 8, ZERO, H, EPI, EH, ) \
+    STEP2(S, S3, 8, 9, ZERO, H, EPI, EH, R4) STEP2(S, S3, 9, 10, ZERO, H, EPI, EH, ) STEP2(S, S3, 10, 11, ZERO, H, EPI, EH, R5) STEP2(S, S3, 11, 12, ZERO, H, EPI, EH, ) \
+    STEP2(S, S3, 12, 13, ZERO, H, EPI, EH, R6) STEP2(S, S3, 13, 14, ZERO, H, EPI, EH, ) STEP2(S, S3, 14, 15, ZERO, H, EPI, EH, R7)
+// two-pass K-tile: pass H = 0 over all n (epilogue EPI0 of half E0), then pass H = 1 (epilogue EPI1 of half E1)
+#define KTILE2(S, S1, S3, ZERO, EPI0, E0, EPI1, E1)                                                 \
+    PASS2(S, S3, ZERO, 0, EPI0, E0, LOADA(S3, 0), LOADA(S3, 1), LOADA(S3, 2), LOADA(S3, 3), LOADA(S3, 4), LOADA(S3, 5), LOADA(S3, 6), LOADA(S3, 7)) \
+    STEP2(S, S3, 15, 0, ZERO, 0, EPI0, E0, )                                                        \
+    PASS2(S, S3, ZERO, 1, EPI1, E1, DMAB(S3, 0), DMAB(S3, 1), DMAB(S3, 2), DMAB(S3, 3), DMAB(S3, 4), DMAB(S3, 5), DMAB(S3, 6), DMAB(S3, 7)) \
+    asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" : RA8(S1), "+v"(FB[1][0]), "+v"(FB[1][1]) :: "memory"); \
+    BARRIER();                                                                                      \
+    READB(0, S1, 0)                                                                                 \
+    MFMAS_H(S, 1, 15, ZERO, 1)                                                                      \
+    EPI1(15, E1)
 #define KTILE(S, S1, S3)                                                                            \
     {                                                                                               \
+        if constexpr (VAR & 32) {                                                                   \
+            if (kt == 0) { KTILE2(S, S1, S3, true, EPI_H, 1, NOEPI, 0) }                            \
+            else if (kt == KT - 1) { KTILE2(S, S1, S3, false, NOEPI, 0, EPI_H, 0) }                 \
+            else { KTILE_Z(S, S1, S3, false) }                                                      \
+        } else                                                                                      \
         if (kt == 0) { KTILE_Z(S, S1, S3, true) } else { KTILE_Z(S, S1, S3, false) }                 \
         advance();                                                                                  \
         if (++kt == KT) {                                                                           \
             kt = 0;                                                                                 \
-            if constexpr (!(VAR & 1)) {                                                             \
+            if constexpr (!(VAR & 1) && !(VAR & 32)) {                                              \
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                  \
                 static_for<0, 64>([&](auto ic) {                                                    \
                     constexpr int m = decltype(ic)::value / 16, n = decltype(ic)::value % 16;       \
@@ -211,6 +255,9 @@ __global__ __launch_bounds__(256) void gemm_w4a(const Args a) {
         if (++it >= total_it) break;                                                                \
     }
 
+    if constexpr (VAR & 32) {   // rows m = 2,3 are read by the first tile's first K-tile before anything wrote them
+        static_for<128, 256>([&](auto ic) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" :: "i"(decltype(ic)::value)); });
+    }
     uint32_t it = 0, kt = 0;
     for (;;) {
         KTILE(0, 1, 3)
@@ -219,6 +266,10 @@ __global__ __launch_bounds__(256) void gemm_w4a(const Args a) {
         KTILE(3, 0, 2)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (VAR & 32) {   // the last tile's rows m = 2,3
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        static_for<0, 16>([&](auto ic) { constexpr int n = decltype(ic)::value; EPI_H(n, 1) });
+    }
     if (blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64() - clk0; a.clk[1] = wall_clock64() - wall0; }
     if (tid == 0) { a.clk[2 + 2 * blockIdx.x] = wall0; a.clk[3 + 2 * blockIdx.x] = wall_clock64(); }
     float* o = a.out + ((uint64_t)blockIdx.x * 256 + tid) * 16;
@@ -287,6 +338,7 @@ int main(int argc, char** argv) {
         case 8: ms = run<8>(a, reps); break;   // quad-coalesced A loads (timing only)
         case 16: ms = run<16>(a, reps); break; // A from an L2-resident tile (timing only)
         case 24: ms = run<24>(a, reps); break; // both
+        case 32: ms = run<32>(a, reps); break; // epilogue reads interleaved with the MFMAs of the K-tiles around a tile boundary
         default: printf("bad variant\n"); return 1;
     }
     const double tf = 2.0 * rows * nq * ld / (ms * 1e-3) / 1e12;
@@ -300,7 +352,7 @@ int main(int argc, char** argv) {
     const double ghz = (double)hclk[0] / (double)hclk[1] * 0.1;
     printf("w4a variant %2d rows %u dim %u: %.3f ms  %7.1f TFLOP/s  sclk %.2f GHz  -> %.1f %% of the MFMA rate at that clock\n", var, rows, dim, ms, tf, ghz,
            100.0 * tf / (2500.0 * ghz / 2.4));
-    if (var) return 0;
+    if (var & ~32) return 0;
 
     std::vector<float> h(256 * 256 * 16);
     hipMemcpy(h.data(), d_out, h.size() * 4, hipMemcpyDeviceToHost);

@@ -477,6 +477,7 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
         typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type frag_t;
         frag_t af[4][2], bf[2][2];
         frag_t bf0[2][2];   // the nh = 0 query fragments stay live from phase 0 to phase 3 (no LDS re-read)
+        bool pace_on = true;   // (thread 0) false after one pacing timeout
 
         for (uint32_t it = 0; it < total_it; ++it) {
             const uint32_t buf = it & 1;
@@ -541,16 +542,20 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
             // block, same XCD) must stay within about one tile of each other or the corpus tile
             // they share falls out of the XCD's L2 and is fetched from HBM once per work-group.
             // Nothing but speed depends on it: relaxed agent-scope counter, bounded spin.
-            if (a.pace_every && kt == 0 && it > 0 && tid == 0) {
+            // (<= ~40 us per wait; a sibling that never arrives -- not resident beside a co-tenant kernel, or
+            // under a counter mode that serialises dispatch -- costs ONE timeout, then this work-group stops pacing)
+            if (a.pace_every && pace_on && kt == 0 && it > 0 && tid == 0) {
                 const uint32_t tix = it / KT;
                 if (tix % a.pace_every == 0) {
                     uint32_t* ctr = a.pace + strip;
                     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t want = a.nqb * (tix / a.pace_every);
-                    for (uint32_t spin = 0; spin < 200000u; ++spin) {
-                        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                    bool ok = false;
+                    for (uint32_t spin = 0; spin < 64u; ++spin) {
+                        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; }
                         __builtin_amdgcn_s_sleep(8);
                     }
+                    pace_on = ok;
                 }
             }
             // ---------------- phase 0: quadrant (0,0), stages A_m0 of the next K-tile
@@ -940,14 +945,20 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         /* pacing of the sibling work-groups (see the phased kernel), here in units of K-tiles: with  \
            the staging two K-tiles ahead no work-group ever waits for HBM, so nothing else keeps   \
            the siblings of a strip together */                                                     \
-        if (a.pace_every && it > 0 && (it % a.pace_every) == 0 && tid == 0) {                      \
+        if (a.pace_every && pace_on && it > 0 && (it % a.pace_every) == 0 && tid == 0) {           \
             uint32_t* ctr = a.pace + strip;                                                        \
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
             const uint32_t want = a.nqb * (it / a.pace_every);                                     \
-            for (uint32_t spin = 0; spin < 200000u; ++spin) {                                      \
-                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break; \
-                __builtin_amdgcn_s_sleep(4);                                                       \
+            bool ok = false;                                                                       \
+            /* <= ~20 us (128 cycles of sleep + an L2 round trip per spin): a sibling that is not resident -- a    \
+               co-tenant kernel (RCCL) holding its CU, a counter mode that serialises dispatch -- costs ONE such  \
+               timeout, after which this work-group stops pacing for the rest of the launch (it used to cost   \
+               200000 spins at every pacing point: tens of ms each, indistinguishable from a hang) */              \
+            for (uint32_t spin = 0; spin < 64u; ++spin) {                                          \
+                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; } \
+                __builtin_amdgcn_s_sleep(2);                                                       \
             }                                                                                      \
+            pace_on = ok;                                                                          \
         }                                                                                          \
         /* L2: the tile's 256 row norms -> LDS slot of its parity (one 1-KB piece, wave 0) */      \
         if (METRIC == M_L2 && !DENSE && first && wave == 0)                                        \
@@ -992,6 +1003,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 
         uint32_t it = 0, kt = 0, tile = t0;
         uint32_t wlog = 0u;   // entries in this wave's log segment (wave-uniform)
+        bool pace_on = true;  // (thread 0) false after one pacing timeout: no more pacing in this launch
         while (it < total_it) {
             W4_ITER(FBx, FBy, W4_LDQ0x, W4_LDQ3x)
             if (it >= total_it) break;

@@ -411,6 +411,8 @@ static StagePlan plan_stages(uint64_t N, uint32_t kp, uint32_t cap, uint32_t max
     const uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(g_env ? g_env : g_auto, cap / (3ull * kp)));
     // sample: N/g^2 rows, at most one round of work-groups (one 256-row tile per work-group of
     // the dense launch)
+    static const uint64_t s_env = [] { const char* e = getenv("VROD_SAMPLE_ROWS"); return e ? (uint64_t)atoll(e) : 0ull; }();   // tuning knob
+    if (s_env) max_sample_rows = (uint32_t)std::min<uint64_t>(s_env, max_sample_rows);
     uint64_t S = std::min<uint64_t>(N / (g * g), max_sample_rows);
     S = std::max<uint64_t>(S, std::min<uint64_t>(N, std::max<uint64_t>(4ull * kp, kRowTile)));
     S = std::min<uint64_t>(round_up(S, kRowTile), N);
@@ -669,8 +671,8 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             launch_scan_mfma(d, scan_dtype, idx->num_cus, s);
             P.scan_pairs.push_back({e0, e1});
             st.scan_launches++;
-            st.scan_bytes += (double)dense_ld * row_bytes_alg;
-            st.scan_flops += 2.0 * nq * (double)sp.S * idx->dim;
+            // (the sample rows are scanned again by the first filtered stage: their time counts, their flops and
+            // bytes do not -- algorithmic work is 2 * nq * N * d and N * row bytes, each row once)
             launch_sample_select(P.scores.as<float>(), dense_ld, sp.S, (int)nq, idx->metric, sp.j, d_thr, s);
         }
         HIP_TRY(hipStreamWaitEvent(s, O.done, 0));
