@@ -37,6 +37,8 @@ pub struct vrod_search_stats {
     pub eps_bound: f32,
     /// 1: the batched fast pass of an F32 handle ran on its bf16 [hi | lo] planes
     pub split_pass: u32,
+    pub band_queries: u32,
+    pub reserved_: u32,
     pub exchange: u32,
 }
 

@@ -76,6 +76,9 @@ typedef struct {
                                  * |canonical| on the direct-L2 stream path, whose bound is relative) */
     float eps_bound;            /* the certificate's bound on that error */
     uint32_t split_pass;        /* 1: the batched fast pass of an F32 handle ran on its bf16 [hi | lo] planes */
+    uint32_t band_queries;      /* of the fallback_queries: resolved by the band pass (one more shared scan that
+                                 * collects the rows within the error bound of the k-th score), not the exact path */
+    uint32_t reserved_;
     uint32_t exchange;          /* multi-device handle: how the per-shard lists reached the merge --
                                  * 0 none (single device), 1 RCCL all-gather, 2 peer copies (VROD_RCCL=0) */
 } vrod_search_stats;

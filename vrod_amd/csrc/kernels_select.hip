@@ -532,6 +532,87 @@ void launch_gather_readback(const uint32_t* d_status, uint32_t nq, uint32_t* d_f
     gather_readback_kernel<<<(nq + 255) / 256 > 0 ? (nq + 255) / 256 : 1, 256, 0, s>>>(d_status, nq, d_flags3, d_max_xn2, d_out);
 }
 
+// ------------------------------------------------------------------ band pass (second chance)
+// A query whose certificate failed still has k candidates with canonical scores; c_k, the k-th of them, is a
+// lower bound of the true k-th best canonical score (the best k of a subset cannot beat the best k of
+// everything).  Every row of the true top-k -- ties at the boundary included -- therefore has
+//     canonical >= c_k   =>   fast >= c_k - eps            (COSINE; mirrored for L2)
+// so ONE more filtered scan with the per-query threshold c_k - eps collects a superset of the answer (the
+// "band"); canonical re-score of the band + exact select by (score, id) is then exact with no certificate.
+// band_prepare_kernel: per failed query f (original index qidx[f]): thr[f] = c_k -/+ 1.01 eps (the scan appends
+// rows STRICTLY better than thr: the slack keeps equality in), counts[f] = 0, ok[f] = 1; a query with fewer than
+// k candidates (c_k undefined) or norms that overflow the bound gets ok[f] = 0 and a threshold nothing passes.
+// Padding queries f >= nf: a threshold nothing passes.
+__global__ __launch_bounds__(256) void band_prepare_kernel(const uint32_t* __restrict__ qidx, uint32_t nf, uint32_t nf_pad,
+                                                           const float* __restrict__ out_scores, uint32_t k, int metric,
+                                                           int eps_mode, float eps_c, const uint32_t* __restrict__ max_qn2_bits,
+                                                           const uint32_t* __restrict__ max_xn2_bits, const float* __restrict__ qn2_all,
+                                                           float* __restrict__ thr, float* __restrict__ qn2, uint32_t* __restrict__ counts,
+                                                           uint32_t* __restrict__ ok) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= nf_pad) return;
+    const float never = metric == M_COSINE ? __builtin_huge_valf() : -__builtin_huge_valf();   // nothing is strictly better
+    counts[f] = 0u;
+    if (f >= nf) { thr[f] = never; qn2[f] = 0.0f; ok[f] = 0u; return; }
+    const uint32_t q = qidx[f];
+    qn2[f] = qn2_all[q];
+    const float ck = out_scores[(uint64_t)q * k + (k - 1)];
+    const float qn = __builtin_sqrtf(__uint_as_float(*max_qn2_bits)), xn = __builtin_sqrtf(__uint_as_float(*max_xn2_bits));
+    const float span = metric == M_COSINE ? qn * xn : (qn + xn) * (qn + xn);
+    if (!(ck == ck) || !(span < 3.0e38f) || eps_mode == 1) { thr[f] = never; ok[f] = 0u; return; }
+    const float eps = (eps_mode == 0 ? eps_c * qn * xn : eps_c * (qn + xn) * (qn + xn)) + eps_c * 2.3509887e-38f;
+    const float slack = 1.01f * eps + 1e-37f;
+    thr[f] = metric == M_COSINE ? ck - slack : ck + slack;
+    ok[f] = 1u;
+}
+
+void launch_band_prepare(const uint32_t* d_qidx, uint32_t nf, uint32_t nf_pad, const float* d_out_scores, uint32_t k, int metric,
+                         int eps_mode, float eps_c, const uint32_t* d_max_qn2_bits, const uint32_t* d_max_xn2_bits,
+                         const float* d_qn2_all, float* d_thr, float* d_qn2, uint32_t* d_counts, uint32_t* d_ok, hipStream_t s) {
+    if (!nf_pad) return;
+    band_prepare_kernel<<<(nf_pad + 255) / 256, 256, 0, s>>>(d_qidx, nf, nf_pad, d_out_scores, k, metric, eps_mode, eps_c, d_max_qn2_bits,
+                                                            d_max_xn2_bits, d_qn2_all, d_thr, d_qn2, d_counts, d_ok);
+}
+
+// prepared query rows of the failed queries, gathered into a dense block [nf_pad][ld] (zero rows for padding); the bf16
+// copy is exact (the prepared rows of a BF16 handle hold bf16 values already)
+__global__ __launch_bounds__(256) void gather_query_rows_kernel(const float* __restrict__ src, const uint32_t* __restrict__ qidx, uint32_t nf,
+                                                                uint32_t ld, float* __restrict__ dst_f32, bf16_t* __restrict__ dst_bf16) {
+    const uint32_t f = blockIdx.x;
+    const bool live = f < nf;
+    const float* row = live ? src + (uint64_t)qidx[f] * ld : nullptr;
+    for (uint32_t j = threadIdx.x; j < ld; j += 256) {
+        const float v = live ? row[j] : 0.0f;
+        dst_f32[(uint64_t)f * ld + j] = v;
+        if (dst_bf16) dst_bf16[(uint64_t)f * ld + j] = f32_to_bf16_rne(v);
+    }
+}
+
+void launch_gather_query_rows(const float* d_src, const uint32_t* d_qidx, uint32_t nf, uint32_t nf_pad, uint32_t ld, float* d_dst_f32,
+                              void* d_dst_bf16, hipStream_t s) {
+    if (!nf_pad) return;
+    gather_query_rows_kernel<<<nf_pad, 256, 0, s>>>(d_src, d_qidx, nf, ld, d_dst_f32, (bf16_t*)d_dst_bf16);
+}
+
+// rows [f][k] of the band pass's results -> rows qidx[f] of the caller's outputs, for the resolved queries only
+__global__ __launch_bounds__(256) void scatter_results_kernel(const uint64_t* __restrict__ ids, const float* __restrict__ scores,
+                                                              const uint32_t* __restrict__ qidx, const uint32_t* __restrict__ resolved,
+                                                              uint32_t k, uint64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+    const uint32_t f = blockIdx.x;
+    if (!resolved[f]) return;
+    const uint32_t q = qidx[f];
+    for (uint32_t i = threadIdx.x; i < k; i += 256) {
+        out_ids[(uint64_t)q * k + i] = ids[(uint64_t)f * k + i];
+        out_scores[(uint64_t)q * k + i] = scores[(uint64_t)f * k + i];
+    }
+}
+
+void launch_scatter_results(const uint64_t* d_ids, const float* d_scores, const uint32_t* d_qidx, const uint32_t* d_resolved, uint32_t nf,
+                            uint32_t k, uint64_t* d_out_ids, float* d_out_scores, hipStream_t s) {
+    if (!nf) return;
+    scatter_results_kernel<<<nf, 256, 0, s>>>(d_ids, d_scores, d_qidx, d_resolved, k, d_out_ids, d_out_scores);
+}
+
 // ------------------------------------------------------------------ exact path output
 // keys: n <= kSelectChunk composite keys built from CANONICAL scores of one query.
 __global__ __launch_bounds__(kSortThreads) void keys_to_output_kernel(

@@ -107,6 +107,10 @@ struct Pending {
     DevBuf q_raw, q_lp, scores, keys_a, keys_b, lists, small, hist, cand_rows, cand_fast, cand_canon;
     DevBuf q_f32;                  // prepared queries (the exact path re-reads them)
     DevBuf q_planes;               // split pass: [nq_pad][3 * ldp] bf16, [hi_j | lo_j | hi_j] per K-tile j
+    // band pass (second chance of the queries whose certificate failed, search_complete)
+    DevBuf band_idx, band_q, band_q_lp, band_planes, band_small, band_ids, band_scores;
+    uint32_t nq_pad = 0;           // of the enqueued search (the list / counter / threshold blocks are sized by it)
+    uint32_t pace_launches = 0;    // scan launches of this search so far (pacing-counter regions)
     uint32_t* h_readback = nullptr;   // pinned host block: status[nq] + 4 scalars, one D2H per search
     size_t h_readback_words = 0;
     hipEvent_t done = nullptr;     // recorded behind the D2H
@@ -505,6 +509,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     // fast norms, NaN/Inf flag, max |q|^2.  No host round trip: the certificate forms its bound
     // on the device and the flag is read with the results.
     const uint32_t nq_pad = (uint32_t)round_up(nq, path == VROD_PATH_MFMA ? 256 : 8);
+    P.nq_pad = nq_pad;
     P.trivial = false;
     if (!P.done) HIP_TRY(hipEventCreateWithFlags(&P.done, hipEventDisableTiming));
     VROD_TRY(P.q_f32.ensure((size_t)nq_pad * idx->ld * 4));
@@ -701,6 +706,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
                                 last ? d_T : nullptr, s);
         }
         HIP_TRY(hipGetLastError());
+        P.pace_launches = pace_launch;
     }
 
     P.eps_mode = eps_mode;
@@ -800,6 +806,121 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
     return rc;
 }
 
+// ------------------------------------------------------------------ band pass
+// Second chance for the queries whose certificate failed on the MFMA path (exact duplicates and near-ties around
+// the k-th result: real embedding corpora are full of them).  The exact path costs one pass over the corpus per 8
+// queries; a batch where most queries fail would take seconds.  Instead ONE more filtered scan, shared by all failed
+// queries, collects for each the rows whose fast score lies within the error bound of c_k, the k-th canonical
+// score the first pass found (kernels_select.hip band_prepare_kernel: a superset of the true top-k, boundary ties
+// included); their canonical re-score and an exact select by (score, id) is the answer -- no certificate needed.
+// A query whose band holds more than kBandKeep rows (thousands of exact duplicates) stays on the exact path.
+static const uint32_t kBandMinQueries = 17;   // up to 16 failed queries: two passes of the exact path are cheaper
+static const uint32_t kBandKeep = kSelectChunk / 2;
+
+static int band_pass(vrod_index* idx, Pending& P, std::vector<uint32_t>& failed, uint32_t max_qn2_bits) {
+    static const bool band_on = [] { const char* e = getenv("VROD_BAND"); return !e || e[0] != '0'; }();
+    const uint32_t nf = (uint32_t)failed.size(), k = P.k;
+    const uint64_t N = P.N;
+    if (!band_on || P.path != VROD_PATH_MFMA || P.eps_mode == 1 || nf < kBandMinQueries || N < k || P.nq_pad == 0) return VROD_OK;
+    vrod_search_stats& st = P.st;
+    hipStream_t s = P.stream;
+    Timer tm(idx, P);
+    const uint32_t nf_pad = (uint32_t)round_up(nf, 256);
+    const uint32_t cap = kSelectChunk;
+    VROD_TRY(P.band_idx.ensure((size_t)nf_pad * 4));
+    VROD_TRY(P.band_q.ensure((size_t)nf_pad * idx->ld * 4));
+    void* bq_lp = nullptr;
+    if (idx->dtype == VROD_DTYPE_BF16) {
+        VROD_TRY(P.band_q_lp.ensure((size_t)nf_pad * idx->ld * 2));
+        bq_lp = P.band_q_lp.p;
+    }
+    VROD_TRY(P.band_small.ensure((size_t)nf_pad * 4 * 5));   // thr | qn2 | ok | resolved | status (scratch)
+    float* b_thr = P.band_small.as<float>();
+    float* b_qn2 = b_thr + nf_pad;
+    uint32_t* b_ok = (uint32_t*)(b_qn2 + nf_pad);
+    uint32_t* b_res = b_ok + nf_pad;
+    uint32_t* b_status = b_res + nf_pad;
+    // the list block of the search ([nq_pad][cap] entries, counters behind it) is free again: its candidates were emitted
+    uint2* d_lists = P.lists.as<uint2>();
+    uint32_t* d_counts = (uint32_t*)((char*)P.lists.p + (size_t)P.nq_pad * cap * 8);
+    float* d_qn2_all = P.small.as<float>();
+    HIP_TRY(hipMemcpyAsync(P.band_idx.p, failed.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+    // the batch's max |q|^2 (the bound's norm): the device copy was consumed with the read-back, flags[3] holds it for this pass
+    HIP_TRY(hipMemcpyAsync(&P.flags[3], &max_qn2_bits, 4, hipMemcpyHostToDevice, s));
+    launch_gather_query_rows(P.q_f32.as<float>(), P.band_idx.as<uint32_t>(), nf, nf_pad, idx->ld, P.band_q.as<float>(), bq_lp, s);
+    launch_band_prepare(P.band_idx.as<uint32_t>(), nf, nf_pad, P.out_scores, k, idx->metric, P.eps_mode, P.eps_c, &P.flags[3], idx->max_xn2_bits,
+                        d_qn2_all, b_thr, b_qn2, d_counts, b_ok, s);
+    MfmaScanArgs a{};
+    a.corpus = idx->corpus; a.queries = idx->dtype == VROD_DTYPE_BF16 ? bq_lp : P.band_q.p; a.xnorm2 = idx->xnorm2; a.qnorm2 = b_qn2; a.thr = b_thr;
+    a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nf_pad; a.nq = nf; a.metric = idx->metric;
+    int scan_dtype = idx->dtype;
+    if (P.split) {
+        VROD_TRY(P.band_planes.ensure((size_t)nf_pad * 3 * idx->ldp * 2));
+        launch_split_rows(P.band_q.as<float>(), nf_pad, idx->ld, idx->ldp, P.band_planes.p, true, s);
+        a.corpus = idx->planes; a.queries = P.band_planes.p;
+        a.ld = 3 * idx->ldp; a.lda_bytes = 2 * idx->ldp * 2; a.a_wrap = 1;
+        scan_dtype = VROD_DTYPE_BF16;
+    }
+    constexpr uint32_t kPaceRegions = 8, kPaceWords = 192;
+    uint32_t* pace_base = P.flags + 64;
+    const double row_bytes_alg = (double)idx->ld * idx->esize;
+    for (uint64_t lo = 0; lo < N;) {
+        const uint64_t end = std::min<uint64_t>(N, lo / kRowTile * kRowTile + (1ull << 24));
+        a.row_begin = (uint32_t)lo; a.row_end = (uint32_t)end;
+        a.pace = pace_base + (P.pace_launches % kPaceRegions) * kPaceWords;
+        a.pace_is_zero = false;   // the regions were used by the search's own launches
+        ++P.pace_launches;
+        size_t e0, e1;
+        tm.arm(e0, e1);
+        launch_scan_mfma(a, scan_dtype, idx->num_cus, s);
+        P.scan_pairs.push_back({e0, e1});
+        st.scan_launches++;
+        st.scan_bytes += (double)(end - lo / kRowTile * kRowTile) * row_bytes_alg;
+        st.scan_flops += 2.0 * nf * (double)(end - lo) * idx->dim;
+        lo = end;
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> hcnt(nf), hok(nf);
+    HIP_TRY(hipMemcpyAsync(hcnt.data(), d_counts, (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hok.data(), b_ok, (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t need = (uint32_t)std::min<uint64_t>(k, N);
+    uint32_t maxc = 0, n_res = 0;
+    std::vector<uint32_t> hres(nf_pad, 0u);
+    for (uint32_t f = 0; f < nf; ++f) {
+        // (a band shorter than k would mean the bound does not hold: never resolve on it)
+        if (hok[f] && hcnt[f] >= need && hcnt[f] <= kBandKeep) { hres[f] = 1u; maxc = std::max(maxc, hcnt[f]); ++n_res; }
+    }
+    if (n_res) {
+        uint32_t kpb = 32;
+        while (kpb < maxc) kpb <<= 1;
+        kpb = std::min<uint32_t>(std::max<uint32_t>(kpb, k), kBandKeep);
+        VROD_TRY(P.cand_rows.ensure((size_t)nf * kpb * 4));
+        VROD_TRY(P.cand_fast.ensure((size_t)nf * kpb * 4));
+        VROD_TRY(P.cand_canon.ensure((size_t)nf * kpb * 4));
+        VROD_TRY(P.band_ids.ensure((size_t)nf * k * 8));
+        VROD_TRY(P.band_scores.ensure((size_t)nf * k * 4));
+        HIP_TRY(hipMemcpyAsync(b_res, hres.data(), (size_t)nf_pad * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(b_status, 0, (size_t)nf_pad * 4, s));
+        // every band row of a resolved query is kept (count <= kpb): sorted by fast score, padded with empty slots
+        launch_list_compact(d_lists, d_counts, cap, (int)nf, idx->metric, kpb, b_thr, b_status, P.cand_rows.as<uint32_t>(), P.cand_fast.as<float>(),
+                            b_qn2 /* T: unused */, s);
+        launch_rescore_candidates(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.band_q.as<float>(), (int)nf, P.cand_rows.as<uint32_t>(), kpb,
+                                  P.cand_canon.as<float>(), s);
+        launch_final_topk(P.cand_rows.as<uint32_t>(), P.cand_fast.as<float>(), P.cand_canon.as<float>(), b_qn2, (int)nf, kpb, k, idx->metric, idmap_of(idx),
+                          P.eps_mode, P.eps_c, &P.flags[3], idx->max_xn2_bits, P.band_ids.as<uint64_t>(), P.band_scores.as<float>(), b_status,
+                          (float*)&P.flags[4], s);
+        launch_scatter_results(P.band_ids.as<uint64_t>(), P.band_scores.as<float>(), P.band_idx.as<uint32_t>(), b_res, nf, k, P.out_ids, P.out_scores, s);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> still;
+        for (uint32_t f = 0; f < nf; ++f)
+            if (!hres[f]) still.push_back(failed[f]);
+        failed.swap(still);
+        st.band_queries = n_res;
+    }
+    return VROD_OK;
+}
+
 // Complete the search in slot P: wait for its status block, then run the exact path for the
 // queries whose certificate failed (enqueued behind whatever the stream holds by now).
 static int search_complete(vrod_index* idx, Pending& P) {
@@ -842,7 +963,9 @@ static int search_complete(vrod_index* idx, Pending& P) {
     for (uint32_t qi = 0; qi < nq; ++qi)
         if (hstatus[qi]) failed.push_back(qi);
     st.fallback_queries = (uint32_t)failed.size();
-    if (P.split && failed.size() * 8 > nq && !idx->split_forced && ++idx->split_bad >= 2) {
+    const bool many_failed = failed.size() * 8 > nq;
+    if (!failed.empty()) VROD_TRY(band_pass(idx, P, failed, hflags[1]));   // resolves most of them with one more shared scan
+    if (P.split && many_failed && !idx->split_forced && ++idx->split_bad >= 2) {
         // the split pass's bound is ~3x wider than the fp32 pass's: on a corpus whose gaps sit
         // inside it (twice now) the fp32 pass is the better fast pass.  The planes are released by
         // the next search that finds the handle idle.
@@ -1188,6 +1311,7 @@ static int composite_end(vrod_index* idx, uint64_t* host_ids, float* host_scores
         idx->stats.path = st.path; idx->stats.kprime = st.kprime;
         idx->stats.scan_launches += st.scan_launches;
         idx->stats.fallback_queries += st.fallback_queries;
+        idx->stats.band_queries += st.band_queries;
         idx->stats.split_pass |= st.split_pass;
         idx->stats.scan_ms = std::max(idx->stats.scan_ms, st.scan_ms);
         idx->stats.total_ms = std::max(idx->stats.total_ms, st.total_ms);
@@ -1357,6 +1481,7 @@ int vrod_index_destroy(vrod_index* idx) {
         if (P.stream) (void)hipStreamDestroy(P.stream);
         P.q_f32.release();
         P.q_planes.release();
+        for (DevBuf* b : {&P.band_idx, &P.band_q, &P.band_q_lp, &P.band_planes, &P.band_small, &P.band_ids, &P.band_scores}) b->release();
         if (P.gexec) (void)hipGraphExecDestroy(P.gexec);
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
         if (P.done) (void)hipEventDestroy(P.done);

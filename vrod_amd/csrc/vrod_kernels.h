@@ -116,6 +116,17 @@ void launch_final_topk(const uint32_t* d_cand_rows, const float* d_cand_fast,
                        uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
                        float* d_max_err, hipStream_t s);
 
+// Band pass (second chance of queries whose certificate failed; kernels_select.hip): thresholds c_k -/+ eps and
+// reset counters for the nf failed queries (original indices d_qidx), their prepared rows gathered into a dense
+// block, and the scatter of the resolved queries' results back to the caller's rows.
+void launch_band_prepare(const uint32_t* d_qidx, uint32_t nf, uint32_t nf_pad, const float* d_out_scores, uint32_t k, int metric,
+                         int eps_mode, float eps_c, const uint32_t* d_max_qn2_bits, const uint32_t* d_max_xn2_bits,
+                         const float* d_qn2_all, float* d_thr, float* d_qn2, uint32_t* d_counts, uint32_t* d_ok, hipStream_t s);
+void launch_gather_query_rows(const float* d_src, const uint32_t* d_qidx, uint32_t nf, uint32_t nf_pad, uint32_t ld, float* d_dst_f32,
+                              void* d_dst_bf16, hipStream_t s);
+void launch_scatter_results(const uint64_t* d_ids, const float* d_scores, const uint32_t* d_qidx, const uint32_t* d_resolved, uint32_t nf,
+                            uint32_t k, uint64_t* d_out_ids, float* d_out_scores, hipStream_t s);
+
 // Exact path: canonical scores (implicit ids) -> exact top-k, via the same select chain with
 // composite keys (ties -> smaller id).  Writes one query's output row.
 void launch_keys_to_output(const uint64_t* d_keys, uint64_t n, int metric, uint32_t k,
