@@ -42,6 +42,11 @@ WORKLOADS = {
     "cfg4": dict(n=40_000_000, dim=768, dtype="bf16", metric="cosine", nq=1024, k=10, bound="mfma"),
     "cfg5": dict(n=10_000_000, dim=1536, dtype="f32", metric="cosine", nq=256, k=1000, bound="mfma"),
     "tiny": dict(n=200_000, dim=768, dtype="bf16", metric="cosine", nq=1024, k=10, bound="mfma"),
+    # cfg3 with exact duplicates (real embedding corpora hold them): 5 % of the rows are 64 copies each of 7812 rows.
+    # cfg3dup: random queries (few land on a duplicated row); cfg3hot: EVERY query is a duplicated row -- all 65 copies tie
+    # at the top, no certificate can hold, the whole batch takes the second chance (band pass)
+    "cfg3dup": dict(n=10_000_000, dim=768, dtype="bf16", metric="cosine", nq=1024, k=10, bound="mfma", dup_groups=7812, dup_copies=64),
+    "cfg3hot": dict(n=10_000_000, dim=768, dtype="bf16", metric="cosine", nq=1024, k=10, bound="mfma", dup_groups=7812, dup_copies=64, hot=True),
 }
 PEAK = {  # /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
     "hbm": (8000.0, "GB/s"),            # HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -111,13 +116,16 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         gathered = torch.empty(world * bufs[0][0].numel(), dtype=torch.uint8, device=dev)
         mi = torch.empty((nq, k), dtype=torch.int64, device=dev)
         ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, max_err=0.0, eps=0.0, split=0,
+    acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, band=0, max_err=0.0, eps=0.0, split=0,
                exchange_ms=0.0, exchange_host_ms=0.0)
     ex_events = []   # (start, stop) on torch's stream around all-gather + merge of every batch
 
     def begin(s):
         _, oi, osc = bufs[s % depth]
-        ix.search_begin_synthetic_device(QUERY_SEED, (first_step + s) * nq, nq, k, oi, osc)
+        if wl.get("hot"):   # the batch's queries ARE duplicated corpus rows (rows [r, r + nq) of the corpus stream)
+            ix.search_begin_synthetic_device(CORPUS_SEED, ((first_step + s) * nq) % (wl["dup_groups"] - nq), nq, k, oi, osc)
+        else:
+            ix.search_begin_synthetic_device(QUERY_SEED, (first_step + s) * nq, nq, k, oi, osc)
 
     if steps > 0:
         begin(0)
@@ -144,6 +152,7 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         acc["scan_bytes"] += st["scan_bytes"]
         acc["launches"] += st["scan_launches"]
         acc["fallback"] += st["fallback_queries"]
+        acc["band"] += st["band_queries"]
         acc["split"] += st["split_pass"]
         acc["max_err"] = max(acc["max_err"], st["max_fast_err"])
         acc["eps"] = st["eps_bound"]
@@ -373,7 +382,16 @@ def main():
     n_total = args.rows or wl["n"]
     lo, hi = shard_range(n_total, rank, world)
     ix = va.Index(wl["dim"], wl["dtype"], wl["metric"], device=dev_index)
-    ix.add_synthetic(CORPUS_SEED, lo, hi - lo)   # shard rows [lo, hi) of the synthetic stream, generated in HBM
+    if wl.get("dup_groups"):
+        if world != 1:
+            raise SystemExit("bench: the duplicate workloads are single-GPU")
+        g, c = wl["dup_groups"], wl["dup_copies"]
+        ix.reserve(n_total)
+        ix.add_synthetic(CORPUS_SEED, 0, n_total - g * c)
+        for _ in range(c):
+            ix.add_synthetic(CORPUS_SEED, 0, g)      # one more copy of rows [0, g)
+    else:
+        ix.add_synthetic(CORPUS_SEED, lo, hi - lo)   # shard rows [lo, hi) of the synthetic stream, generated in HBM
     ix.set_id_offset(lo)
     ix.set_profiling(True)
 
@@ -466,7 +484,8 @@ def main():
                        "corpus_seed": CORPUS_SEED, "query_seed": QUERY_SEED,
                        "batches_in_flight": 1 if os.environ.get("VROD_BENCH_PIPELINE") == "0" else 2},
             "roofline": roofline,
-            "exactness": {"certificate_fallback_queries": fallback_total, "max_fast_err": acc["max_err"], "eps_bound": acc["eps"],
+            "exactness": {"certificate_fallback_queries": fallback_total, "resolved_by_band_pass": acc["band"],
+                          "max_fast_err": acc["max_err"], "eps_bound": acc["eps"],
                           "note": "ids and score bits equal the CPU oracle by construction (canonical re-score + certificate)"},
         }
         if coll:
@@ -489,7 +508,7 @@ def main():
                 vs = torch.empty((nq, wl["k"]), dtype=torch.float32, device=dev)
                 fx.search_synthetic_device(QUERY_SEED, (args.warmup + args.steps - 1) * nq, nq, wl["k"], vi, vs)
                 out["verify_merged_equals_single_device"] = bool(torch.equal(vi, final[0]) and torch.equal(vs.view(torch.int32), final[1].view(torch.int32)))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not wl.get("dup_groups"):
             cb, recall, bit_exact, rs, extra = cpu_baseline(wl, va, torch, dev, n_total)
             out["cpu_baseline"] = cb
             out[f"recall_at_{wl['k']}"] = round(recall, 6)
@@ -497,7 +516,7 @@ def main():
             out["bit_exact_vs_oracle_on_sample"] = bit_exact
             out["parity"] = "unpinned by the reference (vRod holds no scan, tests or vectors): the oracle is a build-authored restatement"
             out.update(extra)
-        if world == 1 and not args.no_host_probe:
+        if world == 1 and not args.no_host_probe and not wl.get("dup_groups"):
             # the boundary as SURVEY.md 8(b) specifies it: vrod_search, host pointers in, results in host
             # memory, synchronous (PCIe both ways inside the call).  Reported beside `value`, never as it.
             hq = va.synth_rows_device(dev_index, QUERY_SEED, 0, nq, wl["dim"]).cpu().numpy()

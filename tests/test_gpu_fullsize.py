@@ -202,3 +202,33 @@ def test_cfg4_eight_shards_merge_to_one_handle(va):
     check_order(ids, sc, n, "cosine")
     assert np.array_equal(mi.cpu().numpy().view(np.uint64), ids)
     assert np.array_equal(bits(ms.cpu().numpy()), bits(sc))
+
+
+def test_cfg3_with_duplicates_full_size_band_pass_properties(va, oracle):
+    """10M x 768 bf16 cosine with 5 % duplicates (64 extra copies of rows 0..7811), a batch of 1024 queries that
+    ARE duplicated rows: all 65 copies tie at the top, no certificate holds, the whole batch takes the band pass.
+    Checked without the oracle: every query's top-10 are the ten SMALLEST ids among its 65 copies (the copies
+    of row r sit at r and at base + c * groups + r), all with the score of the row against itself, which the
+    oracle computes for that one row; and a sample of the queries agrees bit for bit with the EXACT path
+    (canonical score of every row, no fast pass, no certificate, no band)."""
+    n, dim, k, nq, groups, copies = 10_000_000, 768, 10, 1024, 7812, 64
+    base = n - groups * copies
+    with va.Index(dim, "bf16", "cosine") as ix:
+        ix.reserve(n)
+        ix.add_synthetic(CORPUS_SEED, 0, base)
+        for _ in range(copies):
+            ix.add_synthetic(CORPUS_SEED, 0, groups)
+        assert ix.count == n
+        first = 3000
+        ids, sc, st = search_syn(ix, CORPUS_SEED, first, nq, k, path=va.PATH_MFMA)
+        assert st["fallback_queries"] == nq and st["band_queries"] == nq, st     # nobody needed a pass of the exact path
+        r = np.arange(first, first + nq, dtype=np.uint64)
+        want = np.concatenate([r[:, None], base + np.arange(k - 1, dtype=np.uint64)[None, :] * groups + r[:, None]], axis=1)
+        assert np.array_equal(ids, want)
+        rows = oracle.prepare(oracle.synth_rows(CORPUS_SEED, first, 4, dim), 1, 0)
+        self_score = oracle.scan_topk(rows[:1], rows[:1], 1, 0)[1][0, 0]
+        assert np.all(bits(sc[0]) == bits(np.float32(self_score)))
+        assert np.all(sc[:, :1] == sc), "the copies of a row do not all carry the same score"
+        check_order(ids, sc, n, "cosine")
+        ei, es, est = search_syn(ix, CORPUS_SEED, first, 8, k, path=va.PATH_EXACT)
+        assert np.array_equal(ei, ids[:8]) and np.array_equal(bits(es), bits(sc[:8]))

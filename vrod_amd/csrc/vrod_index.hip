@@ -814,14 +814,20 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
 // score the first pass found (kernels_select.hip band_prepare_kernel: a superset of the true top-k, boundary ties
 // included); their canonical re-score and an exact select by (score, id) is the answer -- no certificate needed.
 // A query whose band holds more than kBandKeep rows (thousands of exact duplicates) stays on the exact path.
-static const uint32_t kBandMinQueries = 17;   // up to 16 failed queries: two passes of the exact path are cheaper
+// From how many failed queries on the band pass beats the exact path.  On bf16 rows (or the bf16 planes of an fp32
+// corpus) a band pass of <= 64 queries is the skinny kernel, ONE HBM-bound pass over the corpus (2.8 ms at 15.4 GB),
+// while the exact path's pass of 8 queries is VALU-bound (9 ms there; cfg3dup, 8 failed queries per batch: 22.2 ms
+// per batch through the exact path, 15.9 through the band pass): from 2 queries on.  An fp32 corpus without planes
+// scans at the fp32 matrix rate (16x lower), several exact passes long: only for batches of failures.
+static const uint32_t kBandMinQueriesFast = 2, kBandMinQueriesF32 = 48;
 static const uint32_t kBandKeep = kSelectChunk / 2;
 
 static int band_pass(vrod_index* idx, Pending& P, std::vector<uint32_t>& failed, uint32_t max_qn2_bits) {
     static const bool band_on = [] { const char* e = getenv("VROD_BAND"); return !e || e[0] != '0'; }();
     const uint32_t nf = (uint32_t)failed.size(), k = P.k;
     const uint64_t N = P.N;
-    if (!band_on || P.path != VROD_PATH_MFMA || P.eps_mode == 1 || nf < kBandMinQueries || N < k || P.nq_pad == 0) return VROD_OK;
+    const uint32_t min_q = (idx->dtype == VROD_DTYPE_BF16 || P.split) ? kBandMinQueriesFast : kBandMinQueriesF32;
+    if (!band_on || P.path != VROD_PATH_MFMA || P.eps_mode == 1 || nf < min_q || N < k || P.nq_pad == 0) return VROD_OK;
     vrod_search_stats& st = P.st;
     hipStream_t s = P.stream;
     Timer tm(idx, P);
