@@ -128,12 +128,12 @@ def test_duplicates_tie_break_by_id(va, oracle, path):
     raw = np.concatenate([base] * 60)  # every row 60 times: massive exact ties
     rq = base[:3] + 0.01 * rng.standard_normal((3, 64)).astype(np.float32)
     st = run_case(va, oracle, raw, rq, 25, "f32", "cosine", path)
-    # every query sits next to a base row that exists 60 times -- more than the k' = 41 candidates the
-    # fast pass keeps: the group of exact ties straddles the candidate cut, T equals s_k, no certificate
-    # can separate the kept copies from the left-out ones -> all three queries took the exact path
+    # every query sits next to a base row that exists 60 times -- more than the k' = 33 ... 57 candidates the
+    # fast passes keep: the group of exact ties straddles the candidate cut, T equals s_k, no certificate
+    # can separate the kept copies from the left-out ones -> all three queries took the second chance
     assert st["fallback_queries"] == 3
-    # 40 copies fit inside k': the certificate holds (ties among candidates are ordered by id) -> no fallback
-    st = run_case(va, oracle, np.concatenate([base] * 40), rq, 25, "f32", "cosine", path)
+    # 30 copies fit inside every k': the certificate holds (ties among candidates are ordered by id) -> no fallback
+    st = run_case(va, oracle, np.concatenate([base] * 30), rq, 25, "f32", "cosine", path)
     assert st["fallback_queries"] == 0
 
 

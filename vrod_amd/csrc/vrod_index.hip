@@ -489,6 +489,16 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     if (split) {
         // the split pass's certificate bound is ~3x the fp32 MFMA pass's: more candidates per query
         kp = (uint32_t)std::min<uint64_t>(N, (uint64_t)k + std::max<uint32_t>(32, k / 2));
+    } else if (path == VROD_PATH_MFMA && idx->metric == VROD_METRIC_COSINE) {
+        // Every stage of the batched scan appends ~k' (g - 1) rows per query, and a hit costs its work-group
+        // ~0.35 us (profiles/r02/mfma_experiments.md): fewer candidates, fewer hits.  The margin only has to keep
+        // the k-th canonical score clear of the k'-th fast score by the error bound (1.8e-4 at d = 768 against
+        // ~8e-4 per rank at 10M rows); margins 16 / 10 / 6 / 4 / 2 gave 0 / 0 / 0 / 11 / 937 failed certificates in
+        // 30 720 queries and 12.58-12.65 / 12.53 / 12.51 / 13.27 / 15.44 ms per batch (1.25M-row shard: 1.82 / - /
+        // 1.75 / 1.80 ms); a failed certificate costs a band pass, not a wrong result.  (The L2 bound through the
+        // norm expansion is ~4x wider relative to the gaps: it keeps 16.)
+        static const uint32_t margin_env = [] { const char* e = getenv("VROD_KP_MARGIN"); return e ? (uint32_t)atoi(e) : 0u; }();
+        kp = (uint32_t)std::min<uint64_t>(N, (uint64_t)k + std::max<uint32_t>(margin_env ? margin_env : 8, k / 8));
     }
     st.kprime = kp;
     P.N = N; P.kp = kp;
