@@ -405,13 +405,14 @@ static StagePlan plan_stages(uint64_t N, uint32_t kp, uint32_t cap, uint32_t max
     // number of stages ~ 1/ln g, each costing a launch ramp and a compaction (~40 us): the total is
     // flat between g = 4 and 8 and twice as large at g = 25 (two stages at 10M rows: tried,
     // +0.25 ms per batch).
-    // Round 2, same box, 10M x 768, batch 1024 (profiles/r02/mfma_experiments.md): g = 3 / 4 / 5 / 6 / 8 -> 12.69 / 12.70 /
-    // 12.70 / 12.75 / 12.77-12.87 ms per batch: what a stage pays per hit is the OTHER three waves of the work-group
-    // waiting at the next barrier for the wave that walks a hit column (~0.35 us of work-group time per append, not
-    // 0.1), so large shards take g = 4; a small shard (a stage costs ~40 us of ramp + compaction whatever its size)
-    // keeps g = 8.  VROD_STAGE_GROWTH overrides (tuning).
+    // Round 2, same box, batch 1024 x 768 (profiles/r02/mfma_experiments.md): 10M rows, g = 3 / 4 / 5 / 6 / 8 -> 12.69 / 12.70 /
+    // 12.70 / 12.75 / 12.77-12.87 ms per batch; with the candidate margin at 8, 5M rows g = 4 / 5 / 6 / 8 -> 6.47 / 6.41 / 6.48 /
+    // 6.49, 2.5M -> 3.24 / 3.26 / 3.27 / 3.25, 1.25M -> 1.759 / 1.755 / 1.757 / 1.790.  What a stage pays per hit is the OTHER
+    // three waves of the work-group waiting at the next barrier for the wave that walks a hit column (~0.35 us of
+    // work-group time per append, not 0.1), against ~40 us of ramp + compaction per extra stage: g = 5 at every size.
+    // VROD_STAGE_GROWTH overrides (tuning).
     static const uint64_t g_env = [] { const char* e = getenv("VROD_STAGE_GROWTH"); return e ? (uint64_t)atoi(e) : 0ull; }();
-    const uint64_t g_auto = N >= (4ull << 20) ? 4 : 8;
+    const uint64_t g_auto = 5;
     const uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(g_env ? g_env : g_auto, cap / (3ull * kp)));
     // sample: N/g^2 rows, at most one round of work-groups (one 256-row tile per work-group of
     // the dense launch)
