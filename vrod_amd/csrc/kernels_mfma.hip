@@ -654,6 +654,18 @@ __global__ __launch_bounds__(512) void scan_mfma_phased_kernel(const MfmaKernelA
 // The first K-tile of a corpus tile uses the C = 0 form of the MFMA, so the accumulators are
 // never cleared; the epilogue reads them with v_accvgpr_read.
 // ---------------------------------------------------------------------------------------------
+#ifdef VROD_W4_PROF
+// diagnostic build only (scripts/build_variant.sh prof -DVROD_W4_PROF): shader-clock totals of the filtered 4-wave kernel
+// [0] wave cycles in the kernel  [1] tile epilogues  [2] of which the walk of columns with a hit  [3] wait at the barrier
+// that follows an epilogue  [4] epilogues  [5] epilogues that walked  [6] columns walked  [7] appends  [8] flushes [9] flush cycles
+// [10] counted wait + barrier M  [11] counted wait + barrier E (K-tiles without an epilogue)  [12] K-tiles  [13] phases q0 q1  [14] phases q2 q3
+// (kept in wave-uniform registers while the kernel runs, added to the totals once at its end)
+__device__ unsigned long long g_w4_prof[16];
+__device__ __forceinline__ uint32_t w4_clock() { return (uint32_t)__builtin_readcyclecounter(); }
+#define W4_PROF(...) __VA_ARGS__
+#else
+#define W4_PROF(...)
+#endif
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -691,6 +703,37 @@ __device__ __forceinline__ f32x4 w4_read_acc() {
     return v;
 }
 
+// the same with a wave-uniform run-time tile index t = m * 8 + n (0..63): one computed jump into a table of
+// 36-byte cases (4 reads of 8 B + s_branch).  (As a C++ switch hipcc emits a chain of ~25 scalar branches.)
+__device__ __forceinline__ f32x4 w4_read_acc_dyn(uint32_t t) {
+    f32x4 v;
+    uint32_t tmp;
+#define W4_RD(T)                                                                                    \
+    "v_accvgpr_read_b32 %0, a[4*" #T "]\n\tv_accvgpr_read_b32 %1, a[4*" #T "+1]\n\t"                \
+    "v_accvgpr_read_b32 %2, a[4*" #T "+2]\n\tv_accvgpr_read_b32 %3, a[4*" #T "+3]\n\ts_branch .Lw4rd_e_%=\n\t"
+#define W4_RD8(A, B, C, D, E, F, G, H) W4_RD(A) W4_RD(B) W4_RD(C) W4_RD(D) W4_RD(E) W4_RD(F) W4_RD(G) W4_RD(H)
+    asm volatile("s_getpc_b64 vcc\n"
+                 ".Lw4rd_a_%=:\n\t"
+                 "s_mul_i32 %4, %5, 36\n\t"
+                 "s_add_u32 vcc_lo, vcc_lo, %4\n\t"
+                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                 "s_add_u32 vcc_lo, vcc_lo, .Lw4rd_t_%=-.Lw4rd_a_%=\n\t"
+                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                 "s_setpc_b64 vcc\n"
+                 ".Lw4rd_t_%=:\n\t"
+                 W4_RD8(0, 1, 2, 3, 4, 5, 6, 7) W4_RD8(8, 9, 10, 11, 12, 13, 14, 15)
+                 W4_RD8(16, 17, 18, 19, 20, 21, 22, 23) W4_RD8(24, 25, 26, 27, 28, 29, 30, 31)
+                 W4_RD8(32, 33, 34, 35, 36, 37, 38, 39) W4_RD8(40, 41, 42, 43, 44, 45, 46, 47)
+                 W4_RD8(48, 49, 50, 51, 52, 53, 54, 55) W4_RD8(56, 57, 58, 59, 60, 61, 62, 63)
+                 ".Lw4rd_e_%=:"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=&s"(tmp)
+                 : "s"(t)
+                 : "vcc", "scc");
+#undef W4_RD8
+#undef W4_RD
+    return v;
+}
+
 // Drain the four wave-private log segments (counts in log_cnt[4..7]) into the per-query lists.
 // Called by ALL threads at the same program point, after a barrier that follows every wave's
 // appends; the caller's waves reset their register counters.
@@ -715,7 +758,8 @@ __device__ __forceinline__ void flush_log_w4(const MfmaKernelArgs& a, const uint
 template <int METRIC>
 __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const float* thr_l, const float* qn2_l, const float* xn_l,
                                                uint32_t row_w, uint32_t ql0, uint32_t qb, uint32_t rel_base,
-                                               uint2* log /* this wave's segment */, uint32_t* log_cnt, int wave, uint32_t& wlog) {
+                                               uint2* log /* this wave's segment */, uint32_t* log_cnt, int wave, uint32_t& wlog
+                                               W4_PROF(, uint32_t (&pc)[16])) {
     const uint32_t wlog_in = wlog;
     // thr_l / qn2_l: the work-group's per-query values in LDS; xn_l: this lane's 4-row group of the
     // tile's row norms in LDS (m = 0), 16 floats apart per m
@@ -745,18 +789,23 @@ __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const fl
             }
         });
     });
-    bool hit[8];
-    bool any = false;
+    // columns (n) that hold a hit, as a wave-uniform bit mask
+    uint32_t colmask = 0u;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        hit[n] = better<METRIC>(best[n], thr[n]);
-        any |= hit[n];
-    }
-    if (__any(any)) {
+    for (int n = 0; n < 8; ++n) colmask |= __any(better<METRIC>(best[n], thr[n])) ? 1u << n : 0u;
+    W4_PROF(const uint32_t pt0 = w4_clock(); pc[4] += 1; if (colmask) pc[5] += 1;)
+    if (colmask) {
+        // Which 16 x 16 tiles (m, n) of such a column hold one: straight-line code, 9 instructions per
+        // tile, bit n * 8 + m of a wave-uniform mask.  The hits themselves are then appended by ONE copy
+        // of code in a run-time loop over the marked tiles, the accumulator registers picked by a
+        // computed jump.  (Unrolled over the 64 tiles the appends were ~100 KB of code per kernel, a
+        // column's 10 KB executed once in a while and fetched from L2 every time: 2000 cycles per
+        // column with the other three waves waiting at the barrier, profiles/r02/q_w4_cycle_profile.txt.)
+        uint64_t tmask = 0ull;
         static_for<0, 8>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
-            if (!__any(hit[n])) return;
-            const uint32_t ql = ql0 + n * 16;
+            if (!(colmask & (1u << n))) return;
+            W4_PROF(pc[6] += 1;)
             static_for<0, 8>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -767,31 +816,45 @@ __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const fl
                 for (int r = 0; r < 4; ++r) sc[r] = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2[n]);
                 const float tb = METRIC == M_COSINE ? __builtin_fmaxf(__builtin_fmaxf(sc[0], sc[1]), __builtin_fmaxf(sc[2], sc[3]))
                                                     : __builtin_fminf(__builtin_fminf(sc[0], sc[1]), __builtin_fminf(sc[2], sc[3]));
-                if (!__any(better<METRIC>(tb, thr[n]))) return;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t row = row_w + m * 16 + r;
-                    const bool hitr = better<METRIC>(sc[r], thr[n]) && row >= a.row_lo && row < a.row_end;
-                    // the wave owns a quarter of the log and counts its entries in a register: a
-                    // ballot and a lane prefix give every hit its slot -- no LDS atomic, no wait.
-                    // (The write stays in asm: as a compiler-visible LDS store it would be preceded
-                    // by s_waitcnt vmcnt(0), see filter_tile.)
-                    const unsigned long long hm = __ballot(hitr);
-                    if (hm == 0ull) continue;
-                    const uint32_t pos = wlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-                    if (hitr) {
-                        if (pos < (uint32_t)kLogCapW4) {
-                            const uint64_t e = ((uint64_t)((ql << 24) | (row - rel_base)) << 32) | __float_as_uint(sc[r]);
-                            asm volatile("ds_write_b64 %0, %1" :: "v"(lds_log_addr + pos * 8u), "v"(e) : "memory");
-                        } else {
-                            global_append(a, qb * kBN + ql, __float_as_uint(sc[r]), row);
-                        }
-                    }
-                    wlog += (uint32_t)__builtin_popcountll(hm);
-                }
+                tmask |= __any(better<METRIC>(tb, thr[n])) ? 1ull << (n * 8 + m) : 0ull;
             });
         });
+#pragma unroll 1
+        while (tmask) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(tmask);
+            tmask &= tmask - 1ull;
+            const uint32_t n = t >> 3, m = t & 7u;
+            const uint32_t ql = ql0 + n * 16;
+            const float thr_n = thr_l[ql];
+            f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+            float qn2_n = 0.0f;
+            if constexpr (METRIC == M_L2) { xv = *reinterpret_cast<const f32x4*>(xn_l + m * 16); qn2_n = qn2_l[ql]; }
+            const f32x4 v = w4_read_acc_dyn(m * 8u + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2_n);
+                const uint32_t row = row_w + m * 16 + r;
+                const bool hitr = better<METRIC>(sc, thr_n) && row >= a.row_lo && row < a.row_end;
+                // the wave owns a quarter of the log and counts its entries in a register: a
+                // ballot and a lane prefix give every hit its slot -- no LDS atomic, no wait.
+                // (The write stays in asm: as a compiler-visible LDS store it would be preceded
+                // by s_waitcnt vmcnt(0), see filter_tile.)
+                const unsigned long long hm = __ballot(hitr);
+                if (hm == 0ull) continue;
+                const uint32_t pos = wlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                if (hitr) {
+                    if (pos < (uint32_t)kLogCapW4) {
+                        const uint64_t e = ((uint64_t)((ql << 24) | (row - rel_base)) << 32) | __float_as_uint(sc);
+                        asm volatile("ds_write_b64 %0, %1" :: "v"(lds_log_addr + pos * 8u), "v"(e) : "memory");
+                    } else {
+                        global_append(a, qb * kBN + ql, __float_as_uint(sc), row);
+                    }
+                }
+                wlog += (uint32_t)__builtin_popcountll(hm);
+            }
+        }
     }
+    W4_PROF(pc[2] += w4_clock() - pt0; pc[7] += wlog - wlog_in;)
     // publish the wave's count for the flush; past half of the segment: ask for one
     if (wlog != wlog_in) {
         const uint32_t cnt_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)log_cnt;
@@ -963,28 +1026,38 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         /* L2: the tile's 256 row norms -> LDS slot of its parity (one 1-KB piece, wave 0) */      \
         if (METRIC == M_L2 && !DENSE && first && wave == 0)                                        \
             VROD_GLDS16(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)tile * kBM) + lane * 16, lds + kLdsXn2 + (tile & 1) * 1024); \
+        W4_PROF(const uint32_t pm0 = w4_clock();)                                                  \
         W4_PHASE(FA0, BX, 0, 0, LDQ0, W4_DMU0)                                                     \
         W4_PHASE(FA0, BY, 0, 1, W4_LDQ1, W4_DMU1)                                                  \
+        W4_PROF(const uint32_t pm1 = w4_clock();)                                                  \
         asm volatile(W4_VMWAIT ::: "memory");                                                      \
         VROD_BARRIER();                                                                            \
+        W4_PROF(const uint32_t pm2 = w4_clock(); pc[10] += pm2 - pm1; pc[13] += pm1 - pm0; pc[12] += 1;)  \
         W4_PHASE(FA1, BY, 1, 1, W4_LDQ2, W4_DMU2)                                                  \
         W4_PHASE(FA1, BX, 1, 0, LDQ3, W4_DMU3)                                                     \
         stage_advance();                                                                           \
+        W4_PROF(const uint32_t pm3 = w4_clock(); pc[14] += pm3 - pm2;)                             \
         const bool last = kt == KT - 1;                                                            \
+        W4_PROF(uint32_t pe0 = 0, pe1 = 0;)                                                        \
         if (last) {                                                                                \
+            W4_PROF(pe0 = w4_clock();)                                                             \
             if constexpr (DENSE)                                                                   \
                 w4_dense_store_tile<METRIC>(a, qn2_l, wc * 128 + fr, tile * kBM + wr * 128 + fg * 4, qb * kBN + wc * 128 + fr); \
             else                                                                                   \
                 w4_filter_tile<METRIC>(a, thr_l, qn2_l, xn_l + (tile & 1) * 256 + wr * 128 + fg * 4,        \
                                        tile * kBM + wr * 128 + fg * 4, wc * 128 + fr, qb, rel_base,          \
-                                       log + wave * kLogCapW4, log_cnt, wave, wlog);                        \
+                                       log + wave * kLogCapW4, log_cnt, wave, wlog W4_PROF(, pc));          \
+            W4_PROF(pe1 = w4_clock(); pc[1] += pe1 - pe0;)                                         \
             kt = 0; ++tile;                                                                        \
         } else ++kt;                                                                               \
         asm volatile(W4_VMWAIT ::: "memory");                                                      \
         VROD_BARRIER();                                                                            \
+        W4_PROF(if (!DENSE && last) pc[3] += w4_clock() - pe1; else pc[11] += w4_clock() - pm3;)   \
         if (!DENSE && last && log_cnt[3] != 0u) {   /* every wave's appends are behind the barrier */ \
+            W4_PROF(const uint32_t pf0 = w4_clock();)                                              \
             flush_log_w4(a, log, log_cnt, qb, rel_base, tid);                                      \
             wlog = 0u;                                                                             \
+            W4_PROF(pc[8] += 1; pc[9] += w4_clock() - pf0;)                                        \
         }                                                                                          \
         ++it;                                                                                      \
     }
@@ -1004,11 +1077,13 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         uint32_t it = 0, kt = 0, tile = t0;
         uint32_t wlog = 0u;   // entries in this wave's log segment (wave-uniform)
         bool pace_on = true;  // (thread 0) false after one pacing timeout: no more pacing in this launch
+        W4_PROF(uint32_t pc[16] = {}; const uint32_t pk0 = w4_clock();)
         while (it < total_it) {
             W4_ITER(FBx, FBy, W4_LDQ0x, W4_LDQ3x)
             if (it >= total_it) break;
             W4_ITER(FBy, FBx, W4_LDQ0y, W4_LDQ3y)
         }
+        W4_PROF(pc[0] = w4_clock() - pk0;)
 #undef W4_LOAD_A1
 #undef W4_LOAD_B1
 #undef W4_PHASE_S
@@ -1030,6 +1105,11 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if constexpr (!DENSE) flush_log_w4(a, log, log_cnt, qb, rel_base, tid);
+        W4_PROF(if (!DENSE && lane < 16) {
+            uint32_t v = 0;
+            static_for<0, 16>([&](auto ic) { v = lane == decltype(ic)::value ? pc[decltype(ic)::value] : v; });
+            atomicAdd(&g_w4_prof[lane], (unsigned long long)v);
+        })
     }
 }
 
@@ -1843,3 +1923,15 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
 }
 
 }  // namespace vrod
+
+#ifdef VROD_W4_PROF
+extern "C" int vrod_debug_w4_prof(unsigned long long* out16, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(vrod::g_w4_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vrod::g_w4_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
