@@ -705,6 +705,9 @@ __device__ __forceinline__ f32x4 w4_read_acc() {
 
 // the same with a wave-uniform run-time tile index t = m * 8 + n (0..63): one computed jump into a table of
 // 36-byte cases (4 reads of 8 B + s_branch).  (As a C++ switch hipcc emits a chain of ~25 scalar branches.)
+#ifndef W4_RD_STRIDE_S
+#define W4_RD_STRIDE_S "36"   // bytes per case; tests/test_gpu_walk.py must fail on a build with any other value
+#endif
 __device__ __forceinline__ f32x4 w4_read_acc_dyn(uint32_t t) {
     f32x4 v;
     uint32_t tmp;
@@ -714,7 +717,7 @@ __device__ __forceinline__ f32x4 w4_read_acc_dyn(uint32_t t) {
 #define W4_RD8(A, B, C, D, E, F, G, H) W4_RD(A) W4_RD(B) W4_RD(C) W4_RD(D) W4_RD(E) W4_RD(F) W4_RD(G) W4_RD(H)
     asm volatile("s_getpc_b64 vcc\n"
                  ".Lw4rd_a_%=:\n\t"
-                 "s_mul_i32 %4, %5, 36\n\t"
+                 "s_mul_i32 %4, %5, " W4_RD_STRIDE_S "\n\t"
                  "s_add_u32 vcc_lo, vcc_lo, %4\n\t"
                  "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
                  "s_add_u32 vcc_lo, vcc_lo, .Lw4rd_t_%=-.Lw4rd_a_%=\n\t"
