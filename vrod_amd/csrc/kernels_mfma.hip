@@ -100,6 +100,8 @@ struct MfmaKernelArgs {
     uint32_t* pace;         // [nstrips] arrival counters of the sibling work-groups (zeroed per launch)
     uint32_t pace_every;    // re-align the siblings of a strip every this many tiles (0 = never)
     uint32_t qb_base;       // 4-wave kernel: first query block of this launch (nqb <= slots per launch)
+    uint32_t dense_group;   // DENSE launch of the 2 x 2 4-wave kernel: write one score per (query, group of 32 rows) -- the
+                            // best of the group -- to dense_out[query][group], dense_ld groups per query
 };
 
 template <int METRIC>
@@ -890,9 +892,45 @@ __device__ __forceinline__ void w4_dense_store_tile(const MfmaKernelArgs& a, con
     });
 }
 
-// SPLIT: the corpus row stride differs from the K extent and a corpus row is walked more than once per
-// tile (bf16 split pass over fp32 rows); a template parameter so that the plain form carries no extra state.
-template <int METRIC, bool DENSE, bool SPLIT>
+// The sample pass only feeds a threshold (the j-th best score of the sample rows, vrod_index.hip): the j-th best of the
+// per-group BESTS is a valid stand-in (at least j rows are that good; it is the exact value unless two of the j best rows
+// share a group) and costs 1/32 of the writes and of the select's reads.  A lane's 32 scores per query column are one
+// group: rows row_w + 16 m + r of the tile, m < 8, r < 4; eight groups per 256-row tile ((wave row, lane >> 4)).
+// The launch covers whole tiles of real rows only (row_end a multiple of 256: the caller's condition for this form) --
+// a per-row mask here costs 32 lane masks in SGPRs, which no longer fit beside the main loop's.
+template <int METRIC>
+__device__ __forceinline__ void w4_groupmax_store_tile(const MfmaKernelArgs& a, const float* qn2_l, const float* xn_l, uint32_t ql0,
+                                                       uint32_t gq0, uint32_t group) {
+    // (opaque per tile: hipcc otherwise hoists the store addresses out of the scan loop, which does not fit beside the
+    //  fragments -- it then parks values in the accumulator file, scripts/audit_w4.py)
+    asm volatile("" : "+v"(gq0), "+v"(group));
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const uint32_t off0 = gq0 * a.dense_ld + group, step = 16u * a.dense_ld;   // nq_pad * dense_ld < 2^32 (launcher)
+    // one query column at a time, its best stored at once: one running best and four scores live (walking the row tiles
+    // outermost, as the filter does, hipcc kept all 256 scores in flight here and spilled the fragments)
+    static_for<0, 8>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        const float qn2 = METRIC == M_L2 ? qn2_l[ql0 + n * 16] : 0.0f;
+        float best = worst_score(METRIC);
+        static_for<0, 8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (METRIC == M_L2) xv = *reinterpret_cast<const f32x4*>(xn_l + m * 16);
+            const f32x4 v = w4_read_acc<(m * 8 + n) * 4>();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = METRIC == M_COSINE ? v[r] : __builtin_fmaf(-2.0f, v[r], xv[r] + qn2);
+                best = METRIC == M_COSINE ? __builtin_fmaxf(best, sc) : __builtin_fminf(best, sc);
+            }
+        });
+        if (group < a.dense_ld) a.dense_out[off0 + (uint32_t)n * step] = best;
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// DENSE: 0 = filtered launch, 1 = sample pass writing every score, 2 = sample pass writing group bests (one kernel per
+// form: with both sample epilogues in one function hipcc ran out of VGPRs and went into the accumulator file).
+template <int METRIC, int DENSE, bool SPLIT>
 __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // makes the kernel descriptor allocate a[0:255]
@@ -1029,7 +1067,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
             pace_on = ok;                                                                          \
         }                                                                                          \
         /* L2: the tile's 256 row norms -> LDS slot of its parity (one 1-KB piece, wave 0) */      \
-        if (METRIC == M_L2 && !DENSE && first && wave == 0)                                        \
+        if (METRIC == M_L2 && DENSE != 1 && first && wave == 0)                                    \
             VROD_GLDS16(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)tile * kBM) + lane * 16, lds + kLdsXn2 + (tile & 1) * 1024); \
         W4_PROF(const uint32_t pm0 = w4_clock();)                                                  \
         W4_PHASE(FA0, BX, 0, 0, LDQ0, W4_DMU0)                                                     \
@@ -1046,7 +1084,10 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         W4_PROF(uint32_t pe0 = 0, pe1 = 0;)                                                        \
         if (last) {                                                                                \
             W4_PROF(pe0 = w4_clock();)                                                             \
-            if constexpr (DENSE)                                                                   \
+            if constexpr (DENSE == 2)                                                              \
+                w4_groupmax_store_tile<METRIC>(a, qn2_l, xn_l + (tile & 1) * 256 + wr * 128 + fg * 4, wc * 128 + fr, \
+                                               qb * kBN + wc * 128 + fr, ((tile - a.tile_first) * 2 + wr) * 4 + fg); \
+            else if constexpr (DENSE == 1)                                                         \
                 w4_dense_store_tile<METRIC>(a, qn2_l, wc * 128 + fr, tile * kBM + wr * 128 + fg * 4, qb * kBN + wc * 128 + fr); \
             else                                                                                   \
                 w4_filter_tile<METRIC>(a, thr_l, qn2_l, xn_l + (tile & 1) * 256 + wr * 128 + fg * 4,        \
@@ -1109,7 +1150,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #undef W4_LDP_B
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if constexpr (!DENSE) flush_log_w4(a, log, log_cnt, qb, rel_base, tid);
+        if constexpr (DENSE == 0) flush_log_w4(a, log, log_cnt, qb, rel_base, tid);
         W4_PROF(if (!DENSE && lane < 16) {
             uint32_t v = 0;
             static_for<0, 16>([&](auto ic) { v = lane == decltype(ic)::value ? pc[decltype(ic)::value] : v; });
@@ -1773,6 +1814,19 @@ uint32_t mfma_skinny_max_queries(bool split, uint32_t row_bytes) {
     return skinny_lds_bytes<2>(row_bytes) <= lds_cap ? 32u : skinny_lds_bytes<1>(row_bytes) <= lds_cap ? 16u : 0u;
 }
 
+// does the dense (sample) form of this launch run on the 2 x 2 4-wave kernel, the one form that can write group bests?
+static bool mfma_takes_w4_2x2(const MfmaScanArgs& h, int dtype) {
+    static const bool simple = [] { const char* e = getenv("VROD_MFMA_SIMPLE"); return e && e[0] == '1'; }();
+    static const bool w4 = [] { const char* e = getenv("VROD_MFMA_W4"); return !e || e[0] != '0'; }();
+    static const bool w4a = [] { const char* e = getenv("VROD_MFMA_W4A"); return e && e[0] == '1'; }();
+    const bool split = h.a_wrap != 0;
+    if (dtype != DT_BF16 || simple || !(w4 || split)) return false;
+    const uint32_t ld_bytes = h.ld * 2u, qrow = split ? (h.lda_bytes ? h.lda_bytes : ld_bytes) : ld_bytes;
+    if (h.nq > 0 && h.nq <= mfma_skinny_max_queries(split, qrow)) return false;   // the skinny kernel takes it
+    return split || !w4a;
+}
+uint32_t mfma_dense_group_rows(const MfmaScanArgs& h, int dtype) { return mfma_takes_w4_2x2(h, dtype) ? 32u : 0u; }
+
 void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t s) {
     const LaunchEvents lev = g_launch_events;   // attached to the dispatch (first / last of a split batch)
     g_launch_events = LaunchEvents{};
@@ -1796,6 +1850,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     a.row_end = h.row_end;
     a.dense_out = h.dense_out;
     a.dense_ld = h.dense_ld;
+    a.dense_group = (h.dense_out && h.dense_grouped) ? 1u : 0u;   // only ever set by a caller that asked mfma_dense_group_rows()
     static const int pace_env = [] { const char* e = getenv("VROD_MFMA_PACE"); return e ? atoi(e) : 16; }();
     a.pace = h.pace;
     int grid = num_cus / 8 * 8;
@@ -1843,7 +1898,8 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
                               first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr, 0, a);        \
     } while (0)
 // plain bf16 rows: the 4 x 1 kernel (corpus global -> VGPR); the SPLIT form of the pass keeps the 2 x 2 kernel
-#define VROD_MFMA_W4K(MM, DN) do { if (split) VROD_MFMA_W4K_(MM, DN, true); else if (w4a) VROD_MFMA_W4AK(MM, DN); else VROD_MFMA_W4K_(MM, DN, false); } while (0)
+#define VROD_MFMA_W4K(MM, DN) do { if (split) VROD_MFMA_W4K_(MM, DN, true); else if (w4a) VROD_MFMA_W4AK(MM, (DN) != 0); else VROD_MFMA_W4K_(MM, DN, false); } while (0)
+#define VROD_MFMA_W4G(MM) do { if (split) VROD_MFMA_W4K_(MM, 2, true); else VROD_MFMA_W4K_(MM, 2, false); } while (0)
     const bool split = h.a_wrap != 0;
     // VROD_MFMA_W4A=1: the 4 x 1 kernel (corpus global -> VGPR).  Measured on the same box it ties or loses to the
     // 2 x 2 kernel by 1-3 % (profiles/r02/mfma_experiments.md): half the LDS fills, but the A fragments cost the
@@ -1894,12 +1950,15 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
             a.nstrips = 8 * a.strips_per_xcd;
             a.pace_every = (h.pace && a.nqb > 1 && pace_kt > 0) ? (uint32_t)pace_kt : 0u;   // K-tiles
             if (a.pace_every && (qb_base > 0 || !h.pace_is_zero)) (void)hipMemsetAsync(a.pace, 0, a.nstrips * sizeof(uint32_t), s);
-            if (h.metric == M_COSINE) { if (h.dense_out) VROD_MFMA_W4K(M_COSINE, true); else VROD_MFMA_W4K(M_COSINE, false); }
-            else { if (h.dense_out) VROD_MFMA_W4K(M_L2, true); else VROD_MFMA_W4K(M_L2, false); }
+            // (the 4 x 1 kernel has no grouped sample form: mfma_dense_group_rows() says 0 for it)
+            const bool grp = a.dense_group != 0 && (split || !w4a);
+            if (h.metric == M_COSINE) { if (!h.dense_out) VROD_MFMA_W4K(M_COSINE, 0); else if (grp) VROD_MFMA_W4G(M_COSINE); else VROD_MFMA_W4K(M_COSINE, 1); }
+            else { if (!h.dense_out) VROD_MFMA_W4K(M_L2, 0); else if (grp) VROD_MFMA_W4G(M_L2); else VROD_MFMA_W4K(M_L2, 1); }
         }
         return;
     }
 #undef VROD_MFMA_W4K
+#undef VROD_MFMA_W4G
 #undef VROD_MFMA_W4AK
 #undef VROD_MFMA_W4K_
 #define VROD_MFMA_P(TT, MM, GPV, DN)                                                                            \

@@ -326,7 +326,7 @@ constexpr uint32_t kSampleListCap = 2048;
 template <int METRIC>
 __global__ __launch_bounds__(256) void sample_select_kernel(const float* __restrict__ scores, uint64_t score_ld,
                                                             uint32_t n, uint32_t j, float* __restrict__ thr) {
-    __shared__ uint32_t hist[4096];   // pass-1 maxima [256] / candidate list [2048] / radix histogram
+    __shared__ __attribute__((aligned(16))) uint32_t hist[4096];   // keys [<= 2048] / pass-1 maxima [256] + candidate list [2048] / radix histogram
     __shared__ uint32_t ctl[8];
     const float* sc = scores + (uint64_t)blockIdx.x * score_ld;
     const uint32_t tid = threadIdx.x;

@@ -677,10 +677,19 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             const uint32_t nqb = nq_pad / 256;
             const StagePlan sp = plan_stages(N, kp, cap, std::max<uint32_t>(1, (uint32_t)idx->num_cus / nqb) * kRowTile);
             bounds = sp.bounds;
-            const uint32_t dense_ld = (uint32_t)round_up(sp.S, kRowTile);
-            VROD_TRY(P.scores.ensure((size_t)nq_pad * dense_ld * 4));
             MfmaScanArgs d = a;
-            d.row_begin = 0; d.row_end = sp.S; d.dense_out = P.scores.as<float>(); d.dense_ld = dense_ld;
+            d.row_begin = 0; d.row_end = sp.S;
+            // Grouped form where the kernel has it: the threshold is the j-th best of the per-group bests (groups of 32
+            // rows: valid -- at least j rows are that good -- and exact unless two of the j best share a group), 1/32 of
+            // the dense block to write and to select from.  Only while the groups outnumber j by 8x (else: every score).
+            static const bool group_env = [] { const char* e = getenv("VROD_SAMPLE_GROUPED"); return !e || e[0] != '0'; }();
+            const uint32_t grows = group_env ? mfma_dense_group_rows(d, scan_dtype) : 0u;
+            const uint32_t n_groups = grows ? (uint32_t)(round_up(sp.S, kRowTile) / grows) : 0u;
+            const bool grouped = grows && (uint64_t)sp.j * 8 <= n_groups && sp.S % kRowTile == 0;   // whole tiles of real rows
+            const uint32_t dense_ld = grouped ? (uint32_t)round_up(n_groups, 64) : (uint32_t)round_up(sp.S, kRowTile);
+            const uint32_t n_sel = grouped ? n_groups : sp.S;
+            VROD_TRY(P.scores.ensure((size_t)nq_pad * dense_ld * 4));
+            d.dense_out = P.scores.as<float>(); d.dense_ld = dense_ld; d.dense_grouped = grouped;
             d.pace = pace_base; d.pace_is_zero = true; ++pace_launch;
             size_t e0, e1;
             tm.arm(e0, e1);
@@ -689,7 +698,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             st.scan_launches++;
             // (the sample rows are scanned again by the first filtered stage: their time counts, their flops and
             // bytes do not -- algorithmic work is 2 * nq * N * d and N * row bytes, each row once)
-            launch_sample_select(P.scores.as<float>(), dense_ld, sp.S, (int)nq, idx->metric, sp.j, d_thr, s);
+            launch_sample_select(P.scores.as<float>(), dense_ld, n_sel, (int)nq, idx->metric, sp.j, d_thr, s);
         }
         HIP_TRY(hipStreamWaitEvent(s, O.done, 0));
         uint64_t lo = 0;

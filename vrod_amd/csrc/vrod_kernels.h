@@ -183,8 +183,13 @@ struct MfmaScanArgs {
     bool pace_is_zero;      // the caller already cleared them (else the launcher issues a memset)
     float* dense_out;       // non-null: sample pass, write every fast score [nq_pad][dense_ld]
     uint32_t dense_ld;      // (column = row - row_begin; multiple of 256)
+    bool dense_grouped;     // sample pass, grouped form: dense_out is [nq_pad][dense_ld] with ONE score per group of
+                            // mfma_dense_group_rows() consecutive rows (the group's best), dense_ld = groups per query
 };
 void launch_scan_mfma(const MfmaScanArgs& a, int dtype, int num_cus, hipStream_t s);
+// Rows per group of the grouped sample form for this launch (32), or 0 when the kernel that would take it only
+// writes every score (dense_grouped must then stay false).
+uint32_t mfma_dense_group_rows(const MfmaScanArgs& a, int dtype);
 // Largest batch the skinny (HBM-bound, <= 64 queries) form of the MFMA scan takes for bf16 rows of
 // `row_bytes` bytes (split == true: the [hi | lo] planes of an fp32 corpus); 0 = none.
 uint32_t mfma_skinny_max_queries(bool split, uint32_t row_bytes);
