@@ -473,6 +473,12 @@ def main():
             "avg_launch_ms": round(acc["scan_ms"] / max(acc["launches"], 1), 4), work_key: per_launch,
             "timing": "HIP events attached to each scan dispatch on the library's stream (hipExtLaunchKernelGGL start/stop), timed steps only",
         }
+        rows_per_handle = (n_total + world - 1) // world
+        early_env = os.environ.get("VROD_EARLY_SAMPLE")
+        if wl["bound"] == "mfma" and (early_env not in (None, "0") or (early_env is None and rows_per_handle <= 6_000_000)):
+            # (vrod_index.hip: up to 6M rows per handle the next batch's sample pass runs beside this batch's last stage)
+            roofline["overlap"] = ("sample pass of the next batch runs beside this batch's last stage: per-launch times "
+                                   "include waiting for CUs, so achieved/frac understate the kernel; value is wall-clock")
         out = {
             "metric": baseline_metric() if args.workload == "cfg3" and not args.rows else f"queries/sec, {args.workload}",
             "value": round(value, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

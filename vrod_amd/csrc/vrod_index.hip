@@ -115,6 +115,8 @@ struct Pending {
     size_t h_readback_words = 0;
     hipEvent_t done = nullptr;     // recorded behind the D2H
     hipEvent_t scans_done = nullptr;   // recorded behind the last scan launch
+    hipEvent_t mid_done = nullptr;     // recorded behind the second-to-last scan launch of a staged MFMA search (else with scans_done)
+    bool mid_recorded = false;         // ... in the search being enqueued
     std::vector<hipEvent_t> ev;    // profiling events
     size_t ev_used = 0, t0 = 0, t1 = 0;
     std::vector<std::pair<size_t, size_t>> scan_pairs;
@@ -431,6 +433,14 @@ static StagePlan plan_stages(uint64_t N, uint32_t kp, uint32_t cap, uint32_t max
     return p;
 }
 
+// The event behind a search's last scan launch; a search that did not mark an earlier point (mid_done: behind the
+// second-to-last stage of a staged MFMA search) marks it here as well.
+static int record_scans_done(Pending& P, hipStream_t s) {
+    if (!P.mid_recorded) { HIP_TRY(hipEventRecord(P.mid_done, s)); P.mid_recorded = true; }
+    HIP_TRY(hipEventRecord(P.scans_done, s));
+    return VROD_OK;
+}
+
 // Enqueue one search into slot P: every launch up to the D2H of the status block.  Returns
 // without waiting for the device (except on the trivial empty-corpus case).
 static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queries_raw, uint32_t nq, uint32_t k,
@@ -441,6 +451,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     st.k = k;
     P.nq = nq; P.k = k; P.out_ids = d_out_ids; P.out_scores = d_out_scores;
     P.trivial = true;
+    P.mid_recorded = false;
     P.ev_used = 0; P.t0 = P.t1 = 0; P.scan_pairs.clear();
     if (!nq) return VROD_OK;
     hipStream_t s = P.stream;
@@ -619,7 +630,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
                                P.q_f32.as<float>() + (size_t)q0 * idx->ld, nqp, P.scores.as<float>(), score_ld,
                                d_hist, kp, s);
             P.scan_pairs.push_back({a, b});
-            if (q0 + qpp >= nq && !in_graph) HIP_TRY(hipEventRecord(P.scans_done, s));
+            if (q0 + qpp >= nq && !in_graph) VROD_TRY(record_scans_done(P, s));
             st.scan_launches++;
             st.scan_bytes += (double)N * row_bytes_alg;
             st.scan_flops += 2.0 * nqc * (double)N * idx->dim;
@@ -644,12 +655,21 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             if (idx->metric == VROD_METRIC_COSINE) eps_c = 4.1f * 3.f * idx->dim * u + repr;
             else eps_c = 4.1f * (3.f * idx->dim + 4) * u + repr;
         }
-        // The MFMA scans own the whole chip.  The dense sample pass starts when the other slot's
-        // last scan is through, the first filtered stage when that whole search is: the other
-        // search's tail (compaction, re-score, certificate, read-back) then runs beside this
-        // one's head (query preparation, sample selection) and is never held up by a long stage.
+        // The MFMA scans own the whole chip.  Two orders of the two searches in flight:
+        //  late : the sample pass behind the other slot's last scan, the first filtered stage behind its read-back --
+        //         the other search's tail (compaction, re-score, certificate, read-back) and this one's sample + select
+        //         side by side, ~95 us per batch in which nothing else runs (profiles/r02/s_pipeline_timeline_shard.txt);
+        //  early: the sample pass + select (~50 us) in front of the other slot's LAST stage (behind its second-to-last:
+        //         mid_done), the first filtered stage behind that last stage: it starts the moment the other search's
+        //         scans are through and runs beside that search's tail.
+        // Same box, batch 1024 x 768 bf16, early against late: 1.25M rows 1.84-1.85 / 1.87 ms, 2.5M 3.52 / 3.56-3.58,
+        // 5M 6.76 / 6.83, 10M 13.28-13.32 / 13.40-13.41 (-1.4 / -1.5 / -1.0 / -0.7 %).  Early is taken up to 6M rows per
+        // handle: beyond, the gain is under 1 % and the sample pass squeezed beside a 7-ms stage makes that stage's own
+        // launch time (what bench.py's roofline divides by) unreadable.  VROD_EARLY_SAMPLE=0 / 1 forces late / early.
+        static const int early_env = [] { const char* e = getenv("VROD_EARLY_SAMPLE"); return e ? (e[0] != '0' ? 1 : 0) : -1; }();
+        const bool early = early_env >= 0 ? early_env == 1 : N <= 6000000ull;
         Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
-        HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
+        HIP_TRY(hipStreamWaitEvent(s, early ? O.mid_done : O.scans_done, 0));
         const void* qmat = idx->dtype == VROD_DTYPE_BF16 ? q_lp : P.q_f32.p;
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
@@ -700,7 +720,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             // bytes do not -- algorithmic work is 2 * nq * N * d and N * row bytes, each row once)
             launch_sample_select(P.scores.as<float>(), dense_ld, n_sel, (int)nq, idx->metric, sp.j, d_thr, s);
         }
-        HIP_TRY(hipStreamWaitEvent(s, O.done, 0));
+        HIP_TRY(hipStreamWaitEvent(s, early ? O.scans_done : O.done, 0));
         uint64_t lo = 0;
         for (size_t li = 0; li < bounds.size(); ++li) {
             while (lo < bounds[li]) {
@@ -720,7 +740,8 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
                 lo = end;
             }
             const bool last = li + 1 == bounds.size();
-            if (last) HIP_TRY(hipEventRecord(P.scans_done, s));
+            if (li + 2 == bounds.size()) { HIP_TRY(hipEventRecord(P.mid_done, s)); P.mid_recorded = true; }
+            if (last) VROD_TRY(record_scans_done(P, s));
             launch_list_compact(d_lists, d_counts, cap, (int)nq, idx->metric, kp, d_thr, d_status,
                                 last ? P.cand_rows.as<uint32_t>() : nullptr, last ? P.cand_fast.as<float>() : nullptr,
                                 last ? d_T : nullptr, s);
@@ -782,7 +803,8 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
         P.N = N; P.kp = P.g_kp; P.path = P.g_path; P.eps_mode = P.g_eps_mode; P.eps_c = P.g_eps_c; P.split = false;
         HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
         HIP_TRY(hipGraphLaunch(P.gexec, s));
-        HIP_TRY(hipEventRecord(P.scans_done, s));
+        P.mid_recorded = false;
+        VROD_TRY(record_scans_done(P, s));
         HIP_TRY(hipEventRecord(P.done, s));
         return VROD_OK;
     }
@@ -801,7 +823,7 @@ static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_ra
                 P.g_kp = P.kp; P.g_path = P.path; P.g_eps_mode = P.eps_mode; P.g_eps_c = P.eps_c; P.g_st = P.st;
                 HIP_TRY(hipStreamWaitEvent(s, O.scans_done, 0));
                 HIP_TRY(hipGraphLaunch(P.gexec, s));
-                HIP_TRY(hipEventRecord(P.scans_done, s));
+                VROD_TRY(record_scans_done(P, s));
                 HIP_TRY(hipEventRecord(P.done, s));
                 return VROD_OK;
             }
@@ -1464,7 +1486,8 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
             if (hipMalloc((void**)&P.flags, 8192) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
             if (hipMemset(P.flags, 0, 8192) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
             if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&P.scans_done, hipEventDisableTiming) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipEventCreate failed"); break; }
+                hipEventCreateWithFlags(&P.scans_done, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&P.mid_done, hipEventDisableTiming) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipEventCreate failed"); break; }
         }
     } while (0);
     if (rc != VROD_OK) { vrod_index_destroy(idx); return rc; }
@@ -1512,6 +1535,7 @@ int vrod_index_destroy(vrod_index* idx) {
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
         if (P.done) (void)hipEventDestroy(P.done);
         if (P.scans_done) (void)hipEventDestroy(P.scans_done);
+        if (P.mid_done) (void)hipEventDestroy(P.mid_done);
         if (P.h_readback) (void)hipHostFree(P.h_readback);
     }
     if (idx->caller_ev) (void)hipEventDestroy(idx->caller_ev);
