@@ -117,7 +117,7 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         mi = torch.empty((nq, k), dtype=torch.int64, device=dev)
         ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
     acc = dict(scan_ms=0.0, scan_flops=0.0, scan_bytes=0.0, launches=0, fallback=0, band=0, max_err=0.0, eps=0.0, split=0,
-               exchange_ms=0.0, exchange_host_ms=0.0)
+               exchange_ms=0.0, exchange_host_ms=0.0, sample_ms=0.0, sample_launches=0)
     ex_events = []   # (start, stop) on torch's stream around all-gather + merge of every batch
 
     def begin(s):
@@ -148,6 +148,8 @@ def run_steps(ix, wl, steps, first_step, world, rank, dist, va, torch, dev, coll
         if depth == 1 and s + 1 < steps:
             begin(s + 1)
         acc["scan_ms"] += st["scan_ms"]
+        acc["sample_ms"] += st["sample_ms"]                      # of scan_ms: the sample-pass launch (its own kernel form)
+        acc["sample_launches"] += 1 if st["sample_ms"] > 0 else 0
         acc["scan_flops"] += st["scan_flops"]
         acc["scan_bytes"] += st["scan_bytes"]
         acc["launches"] += st["scan_launches"]
@@ -454,6 +456,16 @@ def main():
             kernel = "scan_mfma_w4_kernel" if split or (wl["dtype"] == "bf16" and os.environ.get("VROD_MFMA_W4", "1") != "0") else "scan_mfma_phased_kernel"
             per_launch = factor * acc["scan_flops"] / max(acc["launches"], 1)
             work_key = "algorithmic_flops_per_launch"
+            # the same split the way rocprofv3 --stats shows it: the filtered launches (the kernel that covers the
+            # algorithmic work) and the sample-pass launch (another instantiation; covers none) are two kernel rows
+            nf = acc["launches"] - acc["sample_launches"]
+            tf = acc["scan_ms"] - acc["sample_ms"]
+            by_kernel = {
+                "filtered_launches": {"launches_per_step": nf / max(args.steps, 1), "avg_launch_ms": round(tf / max(nf, 1), 4),
+                                      "frac_without_the_sample_launch": round(factor * acc["scan_flops"] / (tf * 1e-3) / 1e12 / peak, 4) if tf > 0 else None},
+                "sample_launch": {"launches_per_step": acc["sample_launches"] / max(args.steps, 1),
+                                  "avg_launch_ms": round(acc["sample_ms"] / max(acc["sample_launches"], 1), 4)},
+            }
         # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE pass of this same command
         # (counters cannot be read from inside the run): the committed summary, never a live value
         traffic, traffic_source = None, "not measured in this run (rocprofv3 --pmc FETCH_SIZE is a separate pass)"
@@ -473,6 +485,8 @@ def main():
             "avg_launch_ms": round(acc["scan_ms"] / max(acc["launches"], 1), 4), work_key: per_launch,
             "timing": "HIP events attached to each scan dispatch on the library's stream (hipExtLaunchKernelGGL start/stop), timed steps only",
         }
+        if wl["bound"] == "mfma":
+            roofline["by_kernel"] = by_kernel
         rows_per_handle = (n_total + world - 1) // world
         early_env = os.environ.get("VROD_EARLY_SAMPLE")
         if wl["bound"] == "mfma" and (early_env not in (None, "0") or (early_env is None and rows_per_handle <= 6_000_000)):

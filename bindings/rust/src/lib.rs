@@ -38,7 +38,7 @@ pub struct vrod_search_stats {
     /// 1: the batched fast pass of an F32 handle ran on its bf16 [hi | lo] planes
     pub split_pass: u32,
     pub band_queries: u32,
-    pub reserved_: u32,
+    pub sample_ms: f32,
     pub exchange: u32,
 }
 

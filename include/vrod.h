@@ -68,7 +68,7 @@ typedef struct {
     uint32_t nq, k, kprime;     /* kprime = candidates re-scored per query */
     uint32_t scan_launches;     /* launches of the dominant scan kernel */
     uint32_t fallback_queries;  /* queries whose certificate failed -> exact path */
-    float scan_ms;              /* HIP-event time of the scan kernel launches (sum) */
+    float scan_ms;              /* HIP-event time of the scan kernel launches (sum, sample pass included) */
     float total_ms;             /* HIP-event time of the whole device pipeline */
     double scan_bytes;          /* algorithmic corpus bytes the scan launches covered */
     double scan_flops;          /* algorithmic flops (2*Q*N*d) of the scan launches */
@@ -78,7 +78,9 @@ typedef struct {
     uint32_t split_pass;        /* 1: the batched fast pass of an F32 handle ran on its bf16 [hi | lo] planes */
     uint32_t band_queries;      /* of the fallback_queries: resolved by the band pass (one more shared scan that
                                  * collects the rows within the error bound of the k-th score), not the exact path */
-    uint32_t reserved_;
+    float sample_ms;            /* of scan_ms: the sample-pass launch of a staged MFMA search (its own kernel form; it
+                                 * sets the first thresholds and covers no algorithmic work -- its rows are scanned
+                                 * again by the first filtered launch); 0 when the search had none */
     uint32_t exchange;          /* multi-device handle: how the per-shard lists reached the merge --
                                  * 0 none (single device), 1 RCCL all-gather, 2 peer copies (VROD_RCCL=0) */
 } vrod_search_stats;

@@ -36,7 +36,7 @@ class SearchStats(C.Structure):
         ("scan_ms", C.c_float), ("total_ms", C.c_float),
         ("scan_bytes", C.c_double), ("scan_flops", C.c_double),
         ("max_fast_err", C.c_float), ("eps_bound", C.c_float),
-        ("split_pass", C.c_uint32), ("band_queries", C.c_uint32), ("reserved_", C.c_uint32), ("exchange", C.c_uint32),
+        ("split_pass", C.c_uint32), ("band_queries", C.c_uint32), ("sample_ms", C.c_float), ("exchange", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -120,6 +120,7 @@ struct Pending {
     std::vector<hipEvent_t> ev;    // profiling events
     size_t ev_used = 0, t0 = 0, t1 = 0;
     std::vector<std::pair<size_t, size_t>> scan_pairs;
+    int sample_pair = -1;          // index in scan_pairs of the sample-pass launch (-1: none)
     vrod_search_stats st{};
 
     // hipGraph replay of small, launch-bound searches (search_enqueue): the launches of a search
@@ -452,7 +453,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     P.nq = nq; P.k = k; P.out_ids = d_out_ids; P.out_scores = d_out_scores;
     P.trivial = true;
     P.mid_recorded = false;
-    P.ev_used = 0; P.t0 = P.t1 = 0; P.scan_pairs.clear();
+    P.ev_used = 0; P.t0 = P.t1 = 0; P.scan_pairs.clear(); P.sample_pair = -1;
     if (!nq) return VROD_OK;
     hipStream_t s = P.stream;
     Timer tm(idx, P);
@@ -714,6 +715,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             size_t e0, e1;
             tm.arm(e0, e1);
             launch_scan_mfma(d, scan_dtype, idx->num_cus, s);
+            P.sample_pair = (int)P.scan_pairs.size();
             P.scan_pairs.push_back({e0, e1});
             st.scan_launches++;
             // (the sample rows are scanned again by the first filtered stage: their time counts, their flops and
@@ -1047,6 +1049,8 @@ static int search_complete(vrod_index* idx, Pending& P) {
     }
     if (idx->profiling) {
         for (auto& pr : P.scan_pairs) st.scan_ms += tm.ms(pr.first, pr.second);
+        if (P.sample_pair >= 0 && (size_t)P.sample_pair < P.scan_pairs.size())
+            st.sample_ms = tm.ms(P.scan_pairs[P.sample_pair].first, P.scan_pairs[P.sample_pair].second);
         if (idx->profiling >= 2) st.total_ms = tm.ms(P.t0, P.t1);
     }
     idx->stats = st;
@@ -1361,6 +1365,7 @@ static int composite_end(vrod_index* idx, uint64_t* host_ids, float* host_scores
         idx->stats.fallback_queries += st.fallback_queries;
         idx->stats.band_queries += st.band_queries;
         idx->stats.split_pass |= st.split_pass;
+        if (st.scan_ms > idx->stats.scan_ms) idx->stats.sample_ms = st.sample_ms;   // of the shard whose scans took longest
         idx->stats.scan_ms = std::max(idx->stats.scan_ms, st.scan_ms);
         idx->stats.total_ms = std::max(idx->stats.total_ms, st.total_ms);
         idx->stats.scan_bytes += st.scan_bytes; idx->stats.scan_flops += st.scan_flops;
