@@ -452,8 +452,8 @@ def main():
             factor = 3.0 if split else 1.0
             achieved = factor * acc["scan_flops"] / (acc["scan_ms"] * 1e-3) / 1e12 if acc["scan_ms"] else 0.0
             peak, unit = PEAK["mfma_bf16" if wl["dtype"] == "bf16" or split else "mfma_f32"]
-            # bf16: the 4-wave kernel (VROD_MFMA_W4=0 selects the 8-wave phased form); fp32: phased
-            kernel = "scan_mfma_w4_kernel" if split or (wl["dtype"] == "bf16" and os.environ.get("VROD_MFMA_W4", "1") != "0") else "scan_mfma_phased_kernel"
+            # bf16 rows and the bf16 planes of fp32 rows: the 4-wave kernel; fp32 rows without planes: the 8-wave phased one
+            kernel = "scan_mfma_w4_kernel" if split or wl["dtype"] == "bf16" else "scan_mfma_phased_kernel"
             per_launch = factor * acc["scan_flops"] / max(acc["launches"], 1)
             work_key = "algorithmic_flops_per_launch"
             # the same split the way rocprofv3 --stats shows it: the filtered launches (the kernel that covers the

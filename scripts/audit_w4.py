@@ -1,6 +1,6 @@
 """Audit of the asm-owned registers of scan_mfma_w4_kernel / scan_mfma_w4a_kernel (run after every edit).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -S -o /tmp/k.s vrod_amd/csrc/kernels_mfma.hip --cuda-device-only
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -S -o /tmp/k.s vrod_amd/csrc/kernels_mfma_w4.hip --cuda-device-only
     python scripts/audit_w4.py /tmp/k.s
 
 The kernel names a[0:255] literally in its inline-asm MFMAs.  That is only sound when the

@@ -106,6 +106,7 @@ struct Pending {
     uint32_t* flags = nullptr;     // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits, [64..] pacing counters
     DevBuf q_raw, q_lp, scores, keys_a, keys_b, lists, small, hist, cand_rows, cand_fast, cand_canon;
     DevBuf q_f32;                  // prepared queries (the exact path re-reads them)
+    DevBuf dump;                   // MFMA path: spill regions of the 4-wave kernel's hit logs (scratch, mfma_dump_bytes)
     DevBuf q_planes;               // split pass: [nq_pad][3 * ldp] bf16, [hi_j | lo_j | hi_j] per K-tile j
     // band pass (second chance of the queries whose certificate failed, search_complete)
     DevBuf band_idx, band_q, band_q_lp, band_planes, band_small, band_ids, band_scores;
@@ -675,6 +676,8 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         MfmaScanArgs a{};
         a.corpus = idx->corpus; a.queries = qmat; a.xnorm2 = idx->xnorm2; a.qnorm2 = d_qn2; a.thr = d_thr;
         a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.nq = nq; a.metric = idx->metric;
+        VROD_TRY(P.dump.ensure(mfma_dump_bytes(idx->num_cus)));
+        a.dump = P.dump.p;
         int scan_dtype = idx->dtype;
         if (split) {
             // planes of the rows added since the last batched search, and of this batch's queries
@@ -903,6 +906,8 @@ static int band_pass(vrod_index* idx, Pending& P, std::vector<uint32_t>& failed,
     MfmaScanArgs a{};
     a.corpus = idx->corpus; a.queries = idx->dtype == VROD_DTYPE_BF16 ? bq_lp : P.band_q.p; a.xnorm2 = idx->xnorm2; a.qnorm2 = b_qn2; a.thr = b_thr;
     a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nf_pad; a.nq = nf; a.metric = idx->metric;
+    VROD_TRY(P.dump.ensure(mfma_dump_bytes(idx->num_cus)));
+    a.dump = P.dump.p;
     int scan_dtype = idx->dtype;
     if (P.split) {
         VROD_TRY(P.band_planes.ensure((size_t)nf_pad * 3 * idx->ldp * 2));
@@ -1426,7 +1431,11 @@ static int composite_search(vrod_index* idx, const float* queries, bool from_hos
 extern "C" {
 
 const char* vrod_last_error(void) { return g_last_error.c_str(); }
-const char* vrod_version(void) { return "vrod_amd 0.1 (gfx950)"; }
+#ifndef VROD_HIPCC_VERSION
+#define VROD_HIPCC_VERSION "unknown"
+#endif
+// names the compiler that built the device code: the 4-wave scan's register audit was run on THAT compiler's output
+const char* vrod_version(void) { return "vrod_amd 0.3 (gfx950; hipcc " VROD_HIPCC_VERSION "; w4 accumulator audit passed at build)"; }
 
 int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, const int* device_ids,
                       int n_devices) {
@@ -1535,6 +1544,7 @@ int vrod_index_destroy(vrod_index* idx) {
         if (P.stream) (void)hipStreamDestroy(P.stream);
         P.q_f32.release();
         P.q_planes.release();
+        P.dump.release();
         for (DevBuf* b : {&P.band_idx, &P.band_q, &P.band_q_lp, &P.band_planes, &P.band_small, &P.band_ids, &P.band_scores}) b->release();
         if (P.gexec) (void)hipGraphExecDestroy(P.gexec);
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);

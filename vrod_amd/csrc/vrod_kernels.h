@@ -185,8 +185,10 @@ struct MfmaScanArgs {
     uint32_t dense_ld;      // (column = row - row_begin; multiple of 256)
     bool dense_grouped;     // sample pass, grouped form: dense_out is [nq_pad][dense_ld] with ONE score per group of
                             // mfma_dense_group_rows() consecutive rows (the group's best), dense_ld = groups per query
+    void* dump;             // mfma_dump_bytes(num_cus) bytes of scratch: where the 4-wave kernel spills full hit logs (filtered launches)
 };
 void launch_scan_mfma(const MfmaScanArgs& a, int dtype, int num_cus, hipStream_t s);
+size_t mfma_dump_bytes(int num_cus);
 // Rows per group of the grouped sample form for this launch (32), or 0 when the kernel that would take it only
 // writes every score (dense_grouped must then stay false).
 uint32_t mfma_dense_group_rows(const MfmaScanArgs& a, int dtype);
