@@ -1,4 +1,4 @@
-"""Audit of the asm-owned registers of scan_mfma_w4_kernel / scan_mfma_w4a_kernel (run after every edit).
+"""Audit of the asm-owned registers of scan_mfma_w4_kernel (run after every edit).
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -S -o /tmp/k.s vrod_amd/csrc/kernels_mfma_w4.hip --cuda-device-only
     python scripts/audit_w4.py /tmp/k.s
@@ -92,7 +92,7 @@ def audit_asm_loaded_registers(name, body):
 def audit(path):
     text = open(path).read()
     bad = 0
-    for m in re.finditer(r"^(_ZN4vrod\d+scan_mfma_w4a?_kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN4vrod\d+scan_mfma_w4_kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         bad += audit_asm_loaded_registers(name, body)
         inasm = False
@@ -119,6 +119,9 @@ def audit(path):
                     if first_mfma < 0:
                         first_mfma = ln
                 continue
+            if re.search(r"\bm0\b", code):   # M0 is set by the asm LDS-DMA pieces only: the compiler must have no use of its own for it
+                n_out += 1
+                print(f"{name}: compiler names m0: {line.strip()}")
             if "scratch_" in code or ((("v_accvgpr" in code) or re.search(r"\ba\[?\d+", code)) and n_mfma > 0):
                 n_out += 1
                 print(f"{name}: compiler touches an AGPR / scratch: {line.strip()}")
@@ -133,7 +136,7 @@ def audit(path):
                 print(f"{name}: back-edge from line {ln} to {target} (line {labels[target]}) re-enters the region where the compiler uses AGPRs")
         print(f"{name}: {n_mfma} asm MFMAs, {n_pro} compiler AGPR uses in the prologue (accumulators dead), {n_out} violations")
         bad += n_out + (n_mfma == 0)
-    for m in re.finditer(r"\.amdhsa_kernel (_ZN4vrod\d+scan_mfma_w4a?_kernel\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN4vrod\d+scan_mfma_w4_kernel\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
         name, desc = m.group(1), m.group(2)
         acc = int(re.search(r"\.amdhsa_accum_offset (\d+)", desc).group(1))
         nv = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1))

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     const int reps = atoi(argv[2]), rounds = atoi(argv[3]);
     const float thr = atof(argv[4]);
     std::vector<launch_fn> fn;
-    std::vector<clk_fn> clk;
+    std::vector<clk_fn> clk, xcd;
     std::vector<const char*> names;
     for (int i = 5; i < argc; ++i) {
         void* h = dlopen(argv[i], RTLD_NOW | RTLD_LOCAL);
@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
         if (!f) { fprintf(stderr, "%s: no vrod::launch_scan_mfma\n", argv[i]); return 1; }
         fn.push_back((launch_fn)f); names.push_back(argv[i]);
         clk.push_back((clk_fn)dlsym(h, "vrod_debug_w4_clk"));
+        xcd.push_back((clk_fn)dlsym(h, "vrod_debug_w4_xcd"));
     }
     uint16_t *d_c, *d_q; float *d_thr, *d_xn, *d_qn; uint2* d_lists; uint32_t *d_counts, *d_pace;
     (void)hipMalloc(&d_c, (size_t)rows * dim * 2); (void)hipMalloc(&d_q, (size_t)nq * dim * 2);
@@ -58,14 +59,17 @@ int main(int argc, char** argv) {
     vrod::MfmaScanArgs a{};
     a.corpus = d_c; a.queries = d_q; a.xnorm2 = d_xn; a.qnorm2 = d_qn; a.thr = d_thr; a.lists = d_lists; a.counts = d_counts; a.cap = 8192;
     a.ld = dim; a.nq_pad = nq; a.nq = nq; a.row_begin = 0; a.row_end = rows; a.metric = vrod::M_COSINE; a.pace = d_pace; a.pace_is_zero = false;
+    uint32_t* d_claims; (void)hipMalloc(&d_claims, 4096); a.claims = d_claims;
     void* d_dump; (void)hipMalloc(&d_dump, (size_t)256 * 4 * 512 * 132); a.dump = d_dump;   // (builds without the field ignore it: it is the struct's last)
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     std::vector<std::vector<float>> ms(fn.size());
     std::vector<double> appends(fn.size(), 0.0);
     for (size_t v = 0; v < fn.size(); ++v) { fn[v](a, vrod::DT_BF16, 256, 0); }   // warm: code objects, attributes
     (void)hipDeviceSynchronize();
-    unsigned long long ck[8];
+    unsigned long long ck[12];
     for (size_t v = 0; v < fn.size(); ++v) if (clk[v]) clk[v](ck, 1);
+    unsigned long long xk[32];
+    for (size_t v = 0; v < fn.size(); ++v) if (xcd[v]) xcd[v](xk, 1);
     for (int r = 0; r < rounds; ++r)
         for (size_t v = 0; v < fn.size(); ++v) {
             (void)hipMemsetAsync(d_counts, 0, nq * 4, 0);
@@ -87,6 +91,10 @@ int main(int argc, char** argv) {
             printf("    in-kernel clock %.3f GHz, %.1f shader cycles per K-tile, %.1f us per work-group; tile epilogue %.0f cycles + %.0f at the barrier behind it (wave 0)\n",
                    (double)ck[0] / (double)ck[1] * 0.1, (double)ck[0] / (double)ck[3], (double)ck[1] / (double)ck[2] * 0.01,
                    ck[6] ? (double)ck[4] / (double)ck[6] : 0.0, ck[6] ? (double)ck[5] / (double)ck[6] : 0.0);
+        if (xcd[v] && xcd[v](xk, 1) == 0)
+            for (int x = 0; x < 8; ++x) if (xk[x * 4 + 3]) printf("    XCC %d: %llu work-groups, loop avg %.1f us, min %.1f, max %.1f\n", x, xk[x * 4 + 3],
+                (double)xk[x * 4] / (double)xk[x * 4 + 3] * 0.01, (double)(~xk[x * 4 + 2]) * 0.01, (double)xk[x * 4 + 1] * 0.01);
+        if (clk[v] && ck[1]) printf("    per work-group scan loop: min %.1f us, max %.1f us (last launch: first start -> last end %.1f us)\n", (double)(~ck[8]) * 0.01, (double)ck[7] * 0.01, (double)(ck[9] - ~ck[10]) * 0.01);
     }
     return 0;
 }

@@ -49,6 +49,9 @@ def test_duplicate_heavy_batch_is_resolved_by_the_band_pass(va, oracle, dtype, m
     assert np.array_equal(bits(sc), bits(osc))
     assert st["fallback_queries"] >= 200
     assert st["band_queries"] >= 200, st                            # ... and none of them needed a pass of the exact path
+    # the band scan's own fast-vs-canonical differences are part of max_fast_err: the band is a superset of the true
+    # top-k only while they stay inside the bound the band was cut with
+    assert 0 < st["max_fast_err"] <= st["eps_bound"], st
 
 
 def test_band_too_wide_stays_on_the_exact_path(va, oracle):

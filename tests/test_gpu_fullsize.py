@@ -13,6 +13,8 @@ queries, not for a batch of 1024.  What can be checked at full size without it:
 * order: best first, ties by ascending id, ids unique and in range; top-k is a prefix of top-k2.
 
 cfg2 (1M x 768 fp32, one query) is small enough for the oracle itself and is compared directly.
+Since round 3 the three big configs are ALSO compared with the oracle directly at full size, for a few queries each:
+the oracle walks the corpus in chunks of a million rows (conftest.chunked_oracle_topk) and merges the per-chunk lists.
 Corpus = synthetic stream 1, queries = stream 2, generated on the device by the
 same generator the oracle holds (tests/test_gpu_parity.py::test_synth_stream_matches_oracle).
 """
@@ -99,6 +101,17 @@ def test_cfg3_three_routes_agree(cfg3, cfg3_batch):
     assert np.array_equal(iw, ids[700:1000]) and np.array_equal(bits(sw), bits(sc[700:1000]))
 
 
+def test_cfg3_full_size_against_the_chunked_oracle(oracle, cfg3_batch):
+    """ids AND score bits of 8 queries of the 1024-batch over all 10M rows = the CPU oracle (bf16 data, canonical fp32 chain)"""
+    from conftest import chunked_oracle_topk
+    ids, sc, _ = cfg3_batch
+    qs = [0, 1, 137, 511, 700, 1000, 1022, 1023]
+    rq = np.concatenate([oracle.synth_rows(QUERY_SEED, q, 1, D3) for q in qs])
+    oi, osc = chunked_oracle_topk(oracle, CORPUS_SEED, N3, D3, rq, K3, 1, 0)
+    assert np.array_equal(ids[qs], oi), np.argwhere(ids[qs] != oi)[:5]
+    assert np.array_equal(bits(sc[qs]), bits(osc))
+
+
 def test_cfg3_topk_is_a_prefix_of_top100(cfg3, cfg3_batch):
     ids, sc, _ = cfg3_batch
     i100, s100, _ = search_syn(cfg3, QUERY_SEED, 0, 64, 100)
@@ -151,7 +164,7 @@ def test_cfg2_full_size_against_the_oracle(va, oracle):
 
 
 # ------------------------------------------------------------------ cfg5: 10M x 1536 fp32 cosine, batch 256, top-1000
-def test_cfg5_three_routes_agree(va):
+def test_cfg5_three_routes_agree(va, oracle):
     n, d, nq, k = 10_000_000, 1536, 256, 1000
     with va.Index(d, "f32", "cosine") as ix:
         ix.add_synthetic(CORPUS_SEED, 0, n)
@@ -165,6 +178,13 @@ def test_cfg5_three_routes_agree(va):
         i1, s1, st = search_syn(ix, QUERY_SEED, 8, 8, k, path=1)
         assert st["path"] == 1
         assert np.array_equal(i1, ids[8:16]) and np.array_equal(bits(s1), bits(sc[8:16])), "split pass != stream scan"
+    # two queries of the batch against the CPU oracle over all 10M x 1536 fp32 rows, k = 1000 (ids and score bits)
+    from conftest import chunked_oracle_topk
+    qs = [0, 255]
+    rq = np.concatenate([oracle.synth_rows(QUERY_SEED, q, 1, d) for q in qs])
+    oi, osc = chunked_oracle_topk(oracle, CORPUS_SEED, n, d, rq, k, 0, 0, chunk=500_000)
+    assert np.array_equal(ids[qs], oi), np.argwhere(ids[qs] != oi)[:5]
+    assert np.array_equal(bits(sc[qs]), bits(osc))
     # the same corpus without planes: the fp32 matrix-core pass
     from conftest import f32_split
     with f32_split("0"), va.Index(d, "f32", "cosine") as ix:
@@ -175,7 +195,7 @@ def test_cfg5_three_routes_agree(va):
 
 
 # ------------------------------------------------------------------ cfg4: 40M x 768 bf16 cosine, batch 1024, 8 shards of 5M
-def test_cfg4_eight_shards_merge_to_one_handle(va):
+def test_cfg4_eight_shards_merge_to_one_handle(va, oracle):
     """cfg4's own decomposition, on one device: the 8 x 5M-row shards (searched one after the
     other, ids offset by 5M each) merged by vrod_merge_topk_packed_device -- the layout the RCCL
     all-gather delivers -- against ONE handle holding all 40M rows (61 GB resident)."""
@@ -202,6 +222,13 @@ def test_cfg4_eight_shards_merge_to_one_handle(va):
     check_order(ids, sc, n, "cosine")
     assert np.array_equal(mi.cpu().numpy().view(np.uint64), ids)
     assert np.array_equal(bits(ms.cpu().numpy()), bits(sc))
+    # two queries of the batch against the CPU oracle over all 40M rows
+    from conftest import chunked_oracle_topk
+    qs = [0, 1023]
+    rq = np.concatenate([oracle.synth_rows(QUERY_SEED, q, 1, d) for q in qs])
+    oi, osc = chunked_oracle_topk(oracle, CORPUS_SEED, n, d, rq, k, 1, 0, chunk=2_000_000)
+    assert np.array_equal(ids[qs], oi), np.argwhere(ids[qs] != oi)[:5]
+    assert np.array_equal(bits(sc[qs]), bits(osc))
 
 
 def test_cfg3_with_duplicates_full_size_band_pass_properties(va, oracle):

@@ -163,3 +163,90 @@ def test_rejected_add_rolls_every_shard_back(va, oracle):
         ids, sc = ix.search(rq, 10)
     oi, osc = oracle.search(raw, rq, 10, 0, 0)
     assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))
+
+
+def test_merge_waits_for_the_callers_earlier_use_of_the_output_buffers(va, oracle):
+    """The merge of a multi-device handle writes the caller's output buffers on the library's exchange stream: it must be
+    ordered behind what the caller's stream still does with them.  A slow consumer of the previous batch's results is put
+    on a torch stream, the next search is begun on that stream into the SAME buffers: the consumer must have seen the
+    previous batch's ids, not the next batch's (the single-device path has the same ordering)."""
+    import torch
+    dim, n, nq, k = 64, 150_000, 64, 10
+    raw = oracle.synth_rows(61, 0, n, dim, threads=8)
+    dev = torch.device("cuda", 0)
+    with va.Index(dim, "bf16", "cosine", devices=[0, 0]) as ix:
+        ix.add(raw)
+        oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        osc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            ix.search_synthetic_device(62, 0, nq, k, oi, osc)          # batch A, synchronous: results in oi
+            want = oi.clone()
+            # a long-running kernel chain on the caller's stream, then the consumer of batch A's ids
+            junk = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+            for _ in range(40):
+                junk.normal_()
+            seen = oi.clone()
+            ix.search_begin_synthetic_device(62, nq, nq, k, oi, osc)   # batch B into the same buffers, begun behind the consumer
+            ix.search_end()
+        st.synchronize()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(seen, want), "the merge of batch B overwrote the buffers before the caller's stream had read batch A"
+        assert not torch.equal(oi, want)
+
+
+def test_a_device_that_does_not_exist_is_an_error_not_an_abort(va):
+    with pytest.raises(Exception) as e:
+        va.Index(32, "bf16", "cosine", devices=[0, 99])
+    assert "device 99 out of range" in str(e.value)
+    with pytest.raises(Exception) as e:
+        va.Index(32, "bf16", "cosine", device=99)
+    assert "out of range" in str(e.value)
+
+
+def test_without_librccl_the_exchange_falls_back_to_peer_copies(va, oracle):
+    """VROD_RCCL_LIB pointing at something that is no library: a one-time warning, stats.exchange = 2, same bits.
+    (Own process: the library binds librccl once per process.)"""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, ".")
+import vrod_amd as va
+from oracle import oracle as O
+raw = O.synth_rows(71, 0, 140000, 48, threads=4); rq = O.synth_rows(72, 0, 5, 48)
+oi, osc = O.search(raw, rq, 7, 1, 0, threads=4)
+with va.Index(48, "bf16", "cosine", devices=[0, 0, 0]) as ix:
+    ix.add(raw)
+    ids, sc = ix.search(rq, 7)
+    st = ix.last_stats()
+assert st["exchange"] == 2, st
+assert np.array_equal(ids, oi) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VROD_RCCL_LIB="/etc/hostname")
+    env.pop("VROD_RCCL", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    assert "librccl could not be loaded" in r.stderr
+
+
+@pytest.mark.parametrize("devices", [[0, 1], [0, 1, 1]])
+def test_distinct_devices_through_rccl_and_peer_copies(va, oracle, devices):
+    """Two physical devices (skipped on the 1-GPU box): the in-process RCCL all-gather over a communicator of two ranks, an
+    uneven group ([0, 1, 1]: the first device contributes a filler list), against VROD_RCCL=0 and the oracle."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    dim, n, nq, k = 96, 400_000, 33, 9
+    raw = oracle.synth_rows(81, 0, n, dim, threads=8)
+    rq = oracle.synth_rows(82, 0, nq, dim)
+    oi, osc = oracle.search(raw, rq, k, 1, 0, threads=8)
+    for mode, kind in ((None, 1), ("0", 2)):
+        with rccl(mode), va.Index(dim, "bf16", "cosine", devices=devices) as ix:
+            ix.add(raw)
+            ids, sc = ix.search(rq, k)
+            st = ix.last_stats()
+        assert st["exchange"] == kind, st
+        assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))

@@ -119,6 +119,9 @@ def test_bulkinsert_and_searchsimilar_match_oracle(tmp_path, oracle):
         f.write(np.full(3 * dim + 5, 7.0, np.float32).tobytes())       # three orphan rows and a torn fourth
     with open(cdir / "vr_payloads", "a") as f:
         f.write("orphan-a\norphan-b\ntorn")
+    # (a search BEFORE that insert must not see the orphan lines as payloads either)
+    r = run("-d", db, "-c", "alice", "-e", "SEARCHSIMILAR", "-a", "k=1;" + ",".join(repr(float(v)) for v in rq[0]))
+    assert r.returncode == 0 and r.stdout.split("\t")[2] == str(n) and r.stdout.strip().endswith("the-query")
     line = ",".join(repr(float(v)) for v in rq[1]) + ";second-query"
     assert run("-d", db, "-c", "alice", "-e", "INSERT", "-a", line).returncode == 0
     assert os.path.getsize(cdir / "vr_vectors") == (n + 2) * dim * 4

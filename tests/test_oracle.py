@@ -120,3 +120,18 @@ def test_merge_equals_global_scan(oracle):
         parts = [oracle.search(raw[lo:hi], rq, 12, 0, metric, id_offset=lo) for lo, hi in ((0, 1000), (1000, 2100), (2100, 3000))]
         mi, ms = oracle.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), metric)
         assert np.array_equal(mi, full[0]) and np.array_equal(bits(ms), bits(full[1]))
+
+
+def test_chunked_oracle_equals_the_whole(oracle):
+    """conftest.chunked_oracle_topk (the full-size GPU tests' checker: stream generated, prepared and scanned a chunk
+    of rows at a time, per-chunk lists merged) = the oracle over the whole corpus, ids and score bits, both dtypes."""
+    from conftest import chunked_oracle_topk
+    n, dim, k = 70_001, 96, 25
+    rq = oracle.synth_rows(2, 5, 4, dim)
+    raw = oracle.synth_rows(1, 0, n, dim, threads=4)
+    for dtype in (0, 1):
+        for metric in (0, 1):
+            fi, fs = oracle.search(raw, rq, k, dtype, metric, threads=4)
+            ci, cs = chunked_oracle_topk(oracle, 1, n, dim, rq, k, dtype, metric, chunk=16_384, threads=4)
+            assert np.array_equal(fi, ci)
+            assert np.array_equal(fs.view(np.uint32), cs.view(np.uint32))

@@ -80,6 +80,10 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
             a.pace_every = (h.pace && a.nqb > 1 && pace_kt > 0) ? (uint32_t)pace_kt : 0u;   // K-tiles
             if (a.pace_every && (qb_base > 0 || !h.pace_is_zero)) (void)hipMemsetAsync(a.pace, 0, a.nstrips * sizeof(uint32_t), s);
             const int form = !h.dense_out ? 0 : a.dense_group ? 2 : 1;
+            // work stealing (kernels_mfma_w4.hip): the claim bits of this launch start at zero.  VROD_DEBUG_W4_STEAL=0: static shares (A/B runs)
+            static const bool steal_on = [] { const char* e = getenv("VROD_DEBUG_W4_STEAL"); return !e || e[0] != '0'; }();
+            a.claims = (form == 0 && steal_on && h.claims && (size_t)a.nqb * a.nstrips <= kMfmaClaimWords) ? h.claims : nullptr;
+            if (a.claims) (void)hipMemsetAsync(a.claims, 0, (size_t)a.nqb * a.nstrips * sizeof(uint32_t), s);
             launch_mfma_w4(a, h.metric, form, split, grid, s, first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr);
         }
         return;

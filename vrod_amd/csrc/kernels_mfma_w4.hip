@@ -345,6 +345,35 @@ __device__ __forceinline__ void w4_groupmax_store_tile(const MfmaKernelArgs& a, 
     });
 }
 
+// One LDS-DMA piece (1 KB: 64 lanes x 16 B) in asm: global address = the wave-uniform base `sbase` (the K-tile being staged)
+// + the lane's constant 32-bit offset `voff` (row of the piece, swizzled 16-B chunk), LDS destination = the wave-uniform
+// `lds_buf` + the piece's immediate IMM.  As builtin calls with per-lane 64-bit pointers every piece cost a 64-bit vector
+// add for its address (16 per K-tile, issued in the shadow of the MFMAs but issued: one wave per SIMD gets one instruction
+// per ~4 cycles) and an SGPR for its LDS destination (32 of them: hipcc spilled those to VGPR lanes and read them back
+// with v_readlane in front of every piece); here a piece is s_add (M0) + s_nop + the load, the running position lives in two
+// SGPR pairs advanced once per K-tile, and the 16 lane offsets are loop constants (profiles/r03/mfma_experiments.md).
+// Invisible to hipcc's vmcnt bookkeeping, like the counted waits that retire the pieces.  M0 belongs to these statements
+// (it is a reserved register: a clobber would be ignored): scripts/audit_w4.py checks that hipcc itself never names it.
+template <int IMM>
+__device__ __forceinline__ void w4_dma_piece(uint32_t lds_buf, uint32_t voff, const char* sbase) {
+    asm volatile("s_add_u32 m0, %0, %c3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_buf), "v"(voff), "s"(sbase), "i"(IMM) : "scc", "memory");
+}
+// the same in two statements, for the main loop: M0 is written a group of MFMAs ahead of the load that reads it (the wait
+// state the hardware wants between the two then costs no s_nop: 16 fewer instructions per K-tile)
+template <int IMM>
+__device__ __forceinline__ void w4_dma_m0(uint32_t lds_buf) {
+    asm volatile("s_add_u32 m0, %0, %c1" :: "s"(lds_buf), "i"(IMM) : "scc", "memory");
+}
+__device__ __forceinline__ void w4_dma_load(uint32_t voff, const char* sbase) {
+    asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase) : "memory");
+}
+// a pointer hipcc keeps in an SGPR pair ("s" asm operands must be provably wave-uniform)
+__device__ __forceinline__ const char* w4_uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+
 // DENSE: 0 = filtered launch, 1 = sample pass writing every score, 2 = sample pass writing group bests (one kernel per
 // form: with both sample epilogues in one function hipcc ran out of VGPRs and went into the accumulator file).
 template <int METRIC, int DENSE, bool SPLIT>
@@ -362,6 +391,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
     const uint32_t t1 = a.tile_first + (uint32_t)((uint64_t)a.ntiles * (strip + 1) / a.nstrips);
     if (t0 >= t1) return;
 
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;   // (for the asm LDS-DMA destinations)
     // this wave's hit log (filtered launches)
     char* wlog_lds = lds + kLdsDump + (uint32_t)wave * kDumpWaveBytes;
     char* region = a.dump + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * kDumpRegionBytes;   // ... and where a full log is spilled to
@@ -390,50 +420,60 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         qn2_l[tid] = METRIC == M_L2 ? a.qnorm2[qb * kBN + tid] : 0.0f;
         // (published by the prologue's __syncthreads)
         // per-lane source pointers of the K-tile being staged (two K-tiles ahead of the MFMAs)
-        const char* ua_src = a.corpus + st_lane_off_a + (uint64_t)t0 * kBM * lda_bytes;
-        const char* ub_src = a.queries + st_lane_off_b + (uint64_t)qb * kBN * a.ld_bytes;
+        // the K-tile being staged (two K-tiles ahead of the MFMAs): wave-uniform bases, advanced by stage_advance
+        const char* ua_src = w4_uniform_ptr(a.corpus + (uint64_t)t0 * kBM * lda_bytes);
+        const char* ub_src = w4_uniform_ptr(a.queries + (uint64_t)qb * kBN * a.ld_bytes);
+        // this wave's pieces: 4 of the 16 of each unit -- pieces p0 + i + 8 h (i < 4; h = row half of the unit): the lane
+        // offsets of the 8 A and 8 B pieces are loop constants, the LDS destinations immediates behind lds_w + the buffer
+        const uint32_t p0 = ((uint32_t)wave >> 1) * 16u + ((uint32_t)wave & 1u) * 4u;
+        uint32_t voa[8], vob[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            voa[j] = st_lane_off_a + (p0 + (uint32_t)(j & 3) + (uint32_t)(j >> 2) * 8u) * piece_stride_a;
+            vob[j] = st_lane_off_b + (p0 + (uint32_t)(j & 3) + (uint32_t)(j >> 2) * 8u) * piece_stride_b;
+        }
+        const uint32_t lds_w = __builtin_amdgcn_readfirstlane(lds_addr + p0 * 1024u);
         uint32_t st_kt = 0, st_tile = t0, a_kt = 0;   // a_kt: K-tile of the corpus row ua_src points at
         // unit A_mh / B_nh = the 16 pieces (8 rows x 128 B each) of rows [h*64, h*64+64) of both
         // 128-row halves; this wave moves 4 of them: idx = wave*4 + i -> piece (idx>>3)*16 + (idx&7) + h*8
-        auto stage_a = [&](uint32_t buf, int h, int i) {
-            const uint32_t idx = wave * 4 + i;
-            const uint32_t p = (idx >> 3) * 16 + (idx & 7) + h * 8;
-            VROD_GLDS16(ua_src + p * piece_stride_a, lds + (buf & 1) * kStageBytes + p * 1024);
-        };
-        auto stage_b = [&](uint32_t buf, int h, int i) {
-            const uint32_t idx = wave * 4 + i;
-            const uint32_t p = (idx >> 3) * 16 + (idx & 7) + h * 8;
-            VROD_GLDS16(ub_src + p * piece_stride_b, lds + (buf & 1) * kStageBytes + 32768 + p * 1024);
-        };
-        // next K-tile of the strip (clamped at its end: the last K-tile is re-staged, never read)
+        // unit A_mh / B_nh = the 16 pieces (8 rows x 128 B each) of rows [h*64, h*64+64) of both 128-row halves
+#define W4_STAGE_A(BUF, H, I) w4_dma_piece<((I) + 8 * (H)) * 1024>(lds_w + ((BUF) & 1u) * kStageBytes, voa[(I) + 4 * (H)], ua_src);
+#define W4_STAGE_B(BUF, H, I) w4_dma_piece<32768 + ((I) + 8 * (H)) * 1024>(lds_w + ((BUF) & 1u) * kStageBytes, vob[(I) + 4 * (H)], ub_src);
+        // next K-tile of the strip (clamped at its end: the last K-tile is re-staged, never read).  The common case -- the
+        // next K-tile of the same tile -- is two scalar adds behind one compare; the tile boundary is a wave-uniform branch.
+        // (The bases are SGPR pairs now: with per-lane pointers this had to be written with selects, hipcc moved branchy
+        // pointer updates into a scratch array.)
         auto stage_advance = [&]() {
-            // one update site per pointer (uniform deltas picked by selects): written as branches
-            // with in-place updates, hipcc moves the two pointers into a scratch array
-            const bool in_tile = st_kt + 1 < KT;
-            const bool next_tile = !in_tile && st_tile + 1 < t1;
-            // SPLIT: K-tiles 3j, 3j+1, 3j+2 read corpus K-tile 2j, 2j, 2j+1 ([hi_j | lo_j] interleaved: the
-            // hi plane is staged twice in a row, the second time from L2); a_kt = corpus K-tile
-            const bool hold = SPLIT && (st_kt % 3u) == 0u;
-            const int64_t da_in = hold ? 0 : 128;
-            const int64_t a_back = SPLIT ? (int64_t)a_kt * 128 : (int64_t)(KT - 1) * 128;
-            const int64_t da = in_tile ? da_in : next_tile ? (int64_t)kBM * lda_bytes - a_back : 0;
-            const int64_t db = in_tile ? 128 : next_tile ? -(int64_t)(KT - 1) * 128 : 0;
-            if constexpr (SPLIT) a_kt = in_tile ? (hold ? a_kt : a_kt + 1) : next_tile ? 0u : a_kt;
-            st_kt = in_tile ? st_kt + 1 : next_tile ? 0u : st_kt;
-            st_tile += next_tile ? 1u : 0u;
-            ua_src += da;
-            ub_src += db;
+            if (st_kt + 1 < KT) {
+                // SPLIT: K-tiles 3j, 3j+1, 3j+2 read corpus K-tile 2j, 2j, 2j+1 ([hi_j | lo_j] interleaved: the
+                // hi plane is staged twice in a row, the second time from L2); a_kt = corpus K-tile
+                const bool hold = SPLIT && (st_kt % 3u) == 0u;
+                if constexpr (SPLIT) a_kt += hold ? 0u : 1u;
+                ua_src += hold ? 0 : 128;
+                ub_src += 128;
+                ++st_kt;
+            } else if (st_tile + 1 < t1) {
+                const int64_t a_back = SPLIT ? (int64_t)a_kt * 128 : (int64_t)(KT - 1) * 128;
+                ua_src += (int64_t)kBM * lda_bytes - a_back;
+                ub_src -= (int64_t)(KT - 1) * 128;
+                if constexpr (SPLIT) a_kt = 0u;
+                st_kt = 0u;
+                ++st_tile;
+            }
+            // (behind the join hipcc would keep the two bases in VGPRs: an "s" asm operand then prints as v[..])
+            ua_src = w4_uniform_ptr(ua_src);
+            ub_src = w4_uniform_ptr(ub_src);
         };
 
         // ---- prologue: K-tiles 0 and 1 whole, landed; fragments A0, B0 of K-tile 0
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { stage_a(b, h, i); stage_b(b, h, i); }
-            stage_advance();
-        }
+#define W4_STAGE_UNIT(B) W4_STAGE_A(B, 0, 0) W4_STAGE_B(B, 0, 0) W4_STAGE_A(B, 0, 1) W4_STAGE_B(B, 0, 1) W4_STAGE_A(B, 0, 2) W4_STAGE_B(B, 0, 2)   \
+                         W4_STAGE_A(B, 0, 3) W4_STAGE_B(B, 0, 3) W4_STAGE_A(B, 1, 0) W4_STAGE_B(B, 1, 0) W4_STAGE_A(B, 1, 1) W4_STAGE_B(B, 1, 1)   \
+                         W4_STAGE_A(B, 1, 2) W4_STAGE_B(B, 1, 2) W4_STAGE_A(B, 1, 3) W4_STAGE_B(B, 1, 3)
+        W4_STAGE_UNIT(0u)
+        stage_advance();
+        W4_STAGE_UNIT(1u)
+        stage_advance();
+#undef W4_STAGE_UNIT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
@@ -442,48 +482,34 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #define W4_LOAD_B1(FB, NH, L, J) FB[(J) >> 1][(J) & 1] = *reinterpret_cast<const bf16x8*>((L) + b_frag0 + ((NH) * 4 + ((J) >> 1)) * 2048 + (((J) & 1) ? c_off1 : c_off0));
 // (Where in a phase the four DMA pieces go does not matter: all behind the fragment reads +0.2 %, all in front of
 // them -1.1 %, alternating 0.0 % -- profiles/r02/mfma_experiments.md section 8.)
-#ifdef VROD_W4_STAG
-// experiment (-DVROD_W4_STAG): the waves of the odd SIMD pair issue their LDS-DMA pieces one MFMA group later than the
-// others (all four waves leave a barrier together and would otherwise meet at the texture-address unit four times a phase)
+// DM(j, 0): M0 of the phase's j-th piece, DM(j, 1): its load -- a group of MFMAs apart
 #define W4_PHASE_S(FA, FB, MH, NH, ZERO, LD, DM)                                                   \
-    w4_mfma_group<MH, NH, ZERO, 0>(FA, FB); LD(0) LD(1) if constexpr (!STAG) { DM(0) }             \
-    w4_mfma_group<MH, NH, ZERO, 1>(FA, FB); LD(2) LD(3) if constexpr (STAG) { DM(0) }              \
-    w4_mfma_group<MH, NH, ZERO, 2>(FA, FB); LD(4) LD(5) if constexpr (!STAG) { DM(1) }             \
-    w4_mfma_group<MH, NH, ZERO, 3>(FA, FB); LD(6) LD(7) if constexpr (STAG) { DM(1) }              \
-    w4_mfma_group<MH, NH, ZERO, 4>(FA, FB); if constexpr (!STAG) { DM(2) }                         \
-    w4_mfma_group<MH, NH, ZERO, 5>(FA, FB); if constexpr (STAG) { DM(2) }                          \
-    w4_mfma_group<MH, NH, ZERO, 6>(FA, FB); if constexpr (!STAG) { DM(3) }                         \
-    w4_mfma_group<MH, NH, ZERO, 7>(FA, FB); if constexpr (STAG) { DM(3) }
-#else
-#define W4_PHASE_S(FA, FB, MH, NH, ZERO, LD, DM)                                                   \
-    w4_mfma_group<MH, NH, ZERO, 0>(FA, FB); LD(0) LD(1) DM(0)                                      \
-    w4_mfma_group<MH, NH, ZERO, 1>(FA, FB); LD(2) LD(3)                                            \
-    w4_mfma_group<MH, NH, ZERO, 2>(FA, FB); LD(4) LD(5) DM(1)                                      \
-    w4_mfma_group<MH, NH, ZERO, 3>(FA, FB); LD(6) LD(7)                                            \
-    w4_mfma_group<MH, NH, ZERO, 4>(FA, FB); DM(2)                                                  \
-    w4_mfma_group<MH, NH, ZERO, 5>(FA, FB);                                                        \
-    w4_mfma_group<MH, NH, ZERO, 6>(FA, FB); DM(3)                                                  \
+    DM(0, 0) w4_mfma_group<MH, NH, ZERO, 0>(FA, FB); LD(0) LD(1) DM(0, 1)                          \
+    w4_mfma_group<MH, NH, ZERO, 1>(FA, FB); LD(2) LD(3) DM(1, 0)                                   \
+    w4_mfma_group<MH, NH, ZERO, 2>(FA, FB); LD(4) LD(5) DM(1, 1)                                   \
+    w4_mfma_group<MH, NH, ZERO, 3>(FA, FB); LD(6) LD(7) DM(2, 0)                                   \
+    w4_mfma_group<MH, NH, ZERO, 4>(FA, FB); DM(2, 1)                                               \
+    w4_mfma_group<MH, NH, ZERO, 5>(FA, FB); DM(3, 0)                                               \
+    w4_mfma_group<MH, NH, ZERO, 6>(FA, FB); DM(3, 1)                                               \
     w4_mfma_group<MH, NH, ZERO, 7>(FA, FB);
-#endif
 #define W4_PHASE(FA, FB, MH, NH, LD, DM)                                                           \
     if (first) { W4_PHASE_S(FA, FB, MH, NH, true, LD, DM) } else { W4_PHASE_S(FA, FB, MH, NH, false, LD, DM) }
 // Ablation builds (timing only, results wrong; scripts/ubench/lib_ab): -DVROD_W4_ABL_NODMA no LDS-DMA piece in the loop
 // (the two K-tiles of the prologue stay in LDS), -DVROD_W4_ABL_NOBAR no barrier in the loop, -DVROD_W4_ABL_NOEPI no tile epilogue
 #ifdef VROD_W4_ABL_NODMA
-#define W4_DMU0(j)
-#define W4_DMU1(j)
-#define W4_DMU2(j)
-#define W4_DMU3(j)
+#define W4_DMU0(j, L)
+#define W4_DMU1(j, L)
+#define W4_DMU2(j, L)
+#define W4_DMU3(j, L)
 #define W4_VMWAIT "s_waitcnt lgkmcnt(0)"
 #else
-#define W4_DMU0(j) stage_a(it & 1, 0, j);
-#define W4_DMU1(j) stage_b(it & 1, 0, j);
-#define W4_DMU2(j) stage_b(it & 1, 1, j);
-#define W4_DMU3(j) stage_a(it & 1, 1, j);
+#define W4_HALF_A(H, I, LOAD) if constexpr (LOAD) w4_dma_load(voa[(I) + 4 * (H)], ua_src); else w4_dma_m0<((I) + 8 * (H)) * 1024>(lds_w + (it & 1u) * kStageBytes);
+#define W4_HALF_B(H, I, LOAD) if constexpr (LOAD) w4_dma_load(vob[(I) + 4 * (H)], ub_src); else w4_dma_m0<32768 + ((I) + 8 * (H)) * 1024>(lds_w + (it & 1u) * kStageBytes);
+#define W4_DMU0(j, L) W4_HALF_A(0, j, L)
+#define W4_DMU1(j, L) W4_HALF_B(0, j, L)
+#define W4_DMU2(j, L) W4_HALF_B(1, j, L)
+#define W4_DMU3(j, L) W4_HALF_A(1, j, L)
 #define W4_VMWAIT "s_waitcnt vmcnt(16) lgkmcnt(0)"
-#endif
-#ifndef VROD_W4_STAG_SEL
-#define VROD_W4_STAG_SEL (wave & 1)   // which waves take the shifted slots (-DVROD_W4_STAG_SEL=... to try another pairing)
 #endif
 #ifdef VROD_W4_ABL_NOEPI
 #define W4_ABL_EPI false
@@ -503,10 +529,15 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         /* pacing of the sibling work-groups (see the phased kernel), here in units of K-tiles: with  \
            the staging two K-tiles ahead no work-group ever waits for HBM, so nothing else keeps   \
            the siblings of a strip together */                                                     \
-        if (a.pace_every && pace_on && it > 0 && (it % a.pace_every) == 0 && tid == 0) {           \
+        /* (a countdown, not it % pace_every: one wave per SIMD issues one instruction per ~4 cycles, and the   \
+            ~25 scalar instructions of a run-time modulo in front of every K-tile were 3 % of the kernel) */   \
+        if (--pace_left == 0u) {                                                                   \
+          pace_left = a.pace_every;                                                                \
+          ++pace_round;                                                                            \
+          if (pace_on && tid == 0) {                                                               \
             uint32_t* ctr = a.pace + strip;                                                        \
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
-            const uint32_t want = a.nqb * (it / a.pace_every);                                     \
+            const uint32_t want = a.nqb * pace_round;                                              \
             bool ok = false;                                                                       \
             /* <= ~20 us (128 cycles of sleep + an L2 round trip per spin): a sibling that is not resident -- a    \
                co-tenant kernel (RCCL) holding its CU, a counter mode that serialises dispatch -- costs ONE such  \
@@ -517,10 +548,11 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
                 __builtin_amdgcn_s_sleep(2);                                                       \
             }                                                                                      \
             pace_on = ok;                                                                          \
+          }                                                                                        \
         }                                                                                          \
         /* L2: the tile's 256 row norms -> LDS slot of its parity (one 1-KB piece, wave 0) */      \
         if (METRIC == M_L2 && DENSE != 1 && first && wave == 0)                                    \
-            VROD_GLDS16(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)tile * kBM) + lane * 16, lds + kLdsXn2 + (tile & 1) * 1024); \
+            w4_dma_piece<0>(lds_addr + kLdsXn2 + (tile & 1u) * 1024u, (uint32_t)lane * 16u, w4_uniform_ptr(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)tile * kBM))); \
         W4_PROF(const uint32_t pm0 = w4_clock();)                                                  \
         W4_PHASE(FA0, BX, 0, 0, LDQ0, W4_DMU0)                                                     \
         W4_PHASE(FA0, BY, 0, 1, W4_LDQ1, W4_DMU1)                                                  \
@@ -572,24 +604,15 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         uint32_t it = 0, kt = 0, tile = t0;
         uint32_t wlog = 0u, wglob = 0u;   // entries in this wave's hit log / in its spill region (wave-uniform)
         bool pace_on = true;  // (thread 0) false after one pacing timeout: no more pacing in this launch
+        // K-tiles to the next pacing point (wave-uniform countdown; pace_every = 0: starts at 0 and wraps, i.e. never) and how many passed
+        uint32_t pace_left = a.pace_every ? a.pace_every + 1u : 0u, pace_round = 0u;
         W4_PROF(uint32_t pc[16] = {}; const uint32_t pk0 = w4_clock();)
         W4_CLK(const uint64_t ck0 = __builtin_amdgcn_s_memtime(); const uint64_t cr0 = __builtin_amdgcn_s_memrealtime(); uint32_t cke = 0, ckb = 0, ckn = 0;)
-#ifdef VROD_W4_STAG
-#define W4_LOOP                                                                                    \
-            while (it < total_it) {                                                                \
-                W4_ITER(FBx, FBy, W4_LDQ0x, W4_LDQ3x)                                              \
-                if (it >= total_it) break;                                                         \
-                W4_ITER(FBy, FBx, W4_LDQ0y, W4_LDQ3y)                                              \
-            }
-        if (DENSE == 0 && (VROD_W4_STAG_SEL)) { constexpr bool STAG = true; W4_LOOP } else { constexpr bool STAG = false; W4_LOOP }
-#undef W4_LOOP
-#else
         while (it < total_it) {
             W4_ITER(FBx, FBy, W4_LDQ0x, W4_LDQ3x)
             if (it >= total_it) break;
             W4_ITER(FBy, FBx, W4_LDQ0y, W4_LDQ3y)
         }
-#endif
         W4_PROF(pc[0] = w4_clock() - pk0;)
         W4_CLK(if (!DENSE && tid == 0) {
             const uint64_t ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
@@ -606,6 +629,10 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #undef W4_DMU1
 #undef W4_DMU2
 #undef W4_DMU3
+#undef W4_STAGE_A
+#undef W4_STAGE_B
+#undef W4_HALF_A
+#undef W4_HALF_B
 #undef W4_ITER
 #undef W4_LDQ1
 #undef W4_LDQ2

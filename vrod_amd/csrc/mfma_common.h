@@ -73,6 +73,7 @@ struct MfmaKernelArgs {
     uint32_t pace_every;    // re-align the siblings of a strip every this many tiles (0 = never)
     uint32_t qb_base;       // 4-wave kernel: first query block of this launch (nqb <= slots per launch)
     char* dump;             // 4-wave kernel, filtered launches: spill regions of the hit logs, mfma_dump_bytes() (scratch)
+    uint32_t* claims;       // 4-wave kernel, filtered launches: [nqb][nstrips] claim bits of the strips' tail chunks (work stealing), zeroed per launch; null: static shares only
     uint32_t dense_group;   // DENSE launch of the 2 x 2 4-wave kernel: write one score per (query, group of 32 rows) -- the
                             // best of the group -- to dense_out[query][group], dense_ld groups per query
 };

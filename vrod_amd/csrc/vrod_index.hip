@@ -106,6 +106,7 @@ struct Pending {
     uint32_t* flags = nullptr;     // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits, [64..] pacing counters
     DevBuf q_raw, q_lp, scores, keys_a, keys_b, lists, small, hist, cand_rows, cand_fast, cand_canon;
     DevBuf q_f32;                  // prepared queries (the exact path re-reads them)
+    DevBuf claims;                 // MFMA path: claim bits of the 4-wave kernel's work stealing (kMfmaClaimWords words, zeroed per launch by the launcher)
     DevBuf dump;                   // MFMA path: spill regions of the 4-wave kernel's hit logs (scratch, mfma_dump_bytes)
     DevBuf q_planes;               // split pass: [nq_pad][3 * ldp] bf16, [hi_j | lo_j | hi_j] per K-tile j
     // band pass (second chance of the queries whose certificate failed, search_complete)
@@ -205,6 +206,8 @@ struct vrod_index {
         uint32_t nq = 0, k = 0;
         uint64_t* out_ids = nullptr;     // device pointers on groups[0].device
         float* out_scores = nullptr;
+        hipEvent_t caller_ev = nullptr;  // the caller's stream at _begin: the merge writes out_ids / out_scores behind it
+        bool ordered = false;            // ... recorded for this search (device outputs)
     } cslot[2];
     bool composite() const { return !shards.empty(); }
 
@@ -678,6 +681,8 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.nq = nq; a.metric = idx->metric;
         VROD_TRY(P.dump.ensure(mfma_dump_bytes(idx->num_cus)));
         a.dump = P.dump.p;
+        VROD_TRY(P.claims.ensure(kMfmaClaimWords * 4));
+        a.claims = P.claims.as<uint32_t>();
         int scan_dtype = idx->dtype;
         if (split) {
             // planes of the rows added since the last batched search, and of this batch's queries
@@ -908,6 +913,8 @@ static int band_pass(vrod_index* idx, Pending& P, std::vector<uint32_t>& failed,
     a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nf_pad; a.nq = nf; a.metric = idx->metric;
     VROD_TRY(P.dump.ensure(mfma_dump_bytes(idx->num_cus)));
     a.dump = P.dump.p;
+    VROD_TRY(P.claims.ensure(kMfmaClaimWords * 4));
+    a.claims = P.claims.as<uint32_t>();
     int scan_dtype = idx->dtype;
     if (P.split) {
         VROD_TRY(P.band_planes.ensure((size_t)nf_pad * 3 * idx->ldp * 2));
@@ -962,6 +969,9 @@ static int band_pass(vrod_index* idx, Pending& P, std::vector<uint32_t>& failed,
                             b_qn2 /* T: unused */, s);
         launch_rescore_candidates(idx->corpus, idx->dtype, idx->metric, idx->dim, idx->ld, P.band_q.as<float>(), (int)nf, P.cand_rows.as<uint32_t>(), kpb,
                                   P.cand_canon.as<float>(), s);
+        // flags[4]: the band's own observed |fast - canonical| (folded into max_fast_err by search_complete: the band is a
+        // superset of the true top-k only while that stays inside the bound)
+        HIP_TRY(hipMemsetAsync(&P.flags[4], 0, 4, s));
         launch_final_topk(P.cand_rows.as<uint32_t>(), P.cand_fast.as<float>(), P.cand_canon.as<float>(), b_qn2, (int)nf, kpb, k, idx->metric, idmap_of(idx),
                           P.eps_mode, P.eps_c, &P.flags[3], idx->max_xn2_bits, P.band_ids.as<uint64_t>(), P.band_scores.as<float>(), b_status,
                           (float*)&P.flags[4], s);
@@ -1018,8 +1028,8 @@ static int search_complete(vrod_index* idx, Pending& P) {
     for (uint32_t qi = 0; qi < nq; ++qi)
         if (hstatus[qi]) failed.push_back(qi);
     st.fallback_queries = (uint32_t)failed.size();
-    const bool many_failed = failed.size() * 8 > nq;
     if (!failed.empty()) VROD_TRY(band_pass(idx, P, failed, hflags[1]));   // resolves most of them with one more shared scan
+    const bool many_failed = failed.size() * 8 > nq;   // what the band pass could not resolve (duplicates it handled cheaply do not count)
     if (P.split && many_failed && !idx->split_forced && ++idx->split_bad >= 2) {
         // the split pass's bound is ~3x wider than the fp32 pass's: on a corpus whose gaps sit
         // inside it (twice now) the fp32 pass is the better fast pass.  The planes are released by
@@ -1051,6 +1061,11 @@ static int search_complete(vrod_index* idx, Pending& P) {
     if (st.fallback_queries) {
         P.t1 = tm.mark();
         HIP_TRY(hipStreamSynchronize(s));
+        if (st.band_queries) {   // the band's re-score saw its own fast-vs-canonical differences
+            float band_err = 0.f;
+            HIP_TRY(hipMemcpy(&band_err, &P.flags[4], 4, hipMemcpyDeviceToHost));
+            st.max_fast_err = std::max(st.max_fast_err, band_err);
+        }
     }
     if (idx->profiling) {
         for (auto& pr : P.scan_pairs) st.scan_ms += tm.ms(pr.first, pr.second);
@@ -1197,9 +1212,12 @@ static RcclApi& rccl_api() {
     static bool tried = false;
     if (tried) return api;
     tried = true;
-    const char* names[] = {getenv("VROD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // VROD_RCCL_LIB names THE library: when it is set nothing else is tried (a path that does not load means peer copies)
+    const char* env = getenv("VROD_RCCL_LIB");
+    const bool only_env = env && env[0];
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
-        if (!n || !n[0]) continue;
+        if (!n || !n[0] || (only_env && n != env)) continue;
         api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (api.h) break;
         api.why = dlerror();
@@ -1239,10 +1257,29 @@ static int composite_open_exchange(vrod_index* idx) {
     }
     const char* e = getenv("VROD_RCCL");
     idx->use_rccl = !(e && e[0] == '0');   // VROD_RCCL=0: peer copies to the first device instead
+    // peer access between the first device (where the lists are merged) and the others: best effort -- without it the
+    // runtime stages cross-device copies through the host, slower but correct
+    for (size_t u = 1; u < idx->groups.size(); ++u) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, idx->groups[0].device, idx->groups[u].device) == hipSuccess && can) {
+            (void)hipSetDevice(idx->groups[0].device);
+            (void)hipDeviceEnablePeerAccess(idx->groups[u].device, 0);   // (hipErrorPeerAccessAlreadyEnabled is fine)
+            (void)hipSetDevice(idx->groups[u].device);
+            (void)hipDeviceEnablePeerAccess(idx->groups[0].device, 0);
+        }
+        (void)hipGetLastError();
+    }
     if (idx->use_rccl) {
         RcclApi& api = rccl_api();
-        if (!api.h) return fail(VROD_ERR_UNSUPPORTED, "a multi-device handle exchanges its results over RCCL, and librccl could not be loaded (%s); "
-                                "set VROD_RCCL_LIB to its path, or VROD_RCCL=0 for peer copies", api.why.c_str());
+        if (!api.h) {
+            // no collective library: the exchange falls back to peer copies to the first device (stats.exchange = 2), said once
+            static bool warned = false;
+            if (!warned) fprintf(stderr, "vrod: librccl could not be loaded (%s); multi-device handles exchange their lists by peer copies "
+                                         "(set VROD_RCCL_LIB to the library's path for the RCCL all-gather)\n", api.why.c_str());
+            warned = true;
+            idx->use_rccl = false;
+            return VROD_OK;
+        }
         std::vector<int> devs;
         for (auto& G : idx->groups) devs.push_back(G.device);
         std::vector<ncclComm_t> comms(devs.size(), nullptr);
@@ -1256,7 +1293,11 @@ static int composite_open_exchange(vrod_index* idx) {
         fflush(stdout);
         if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
         if (nul >= 0) close(nul);
-        if (ir != ncclSuccess) return fail(VROD_ERR_HIP, "ncclCommInitAll over %zu devices failed: %s", devs.size(), api.GetErrorString(ir));
+        if (ir != ncclSuccess) {
+            fprintf(stderr, "vrod: ncclCommInitAll over %zu devices failed (%s); this handle exchanges its lists by peer copies\n", devs.size(), api.GetErrorString(ir));
+            idx->use_rccl = false;
+            return VROD_OK;
+        }
         for (size_t u = 0; u < devs.size(); ++u) idx->groups[u].comm = comms[u];
     }
     return VROD_OK;
@@ -1304,6 +1345,16 @@ static int composite_begin(vrod_index* idx, const float* queries, bool from_host
             if (!idx->caller_ev) HIP_TRY(hipEventCreateWithFlags(&idx->caller_ev, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(idx->caller_ev, (hipStream_t)caller_stream));
         }
+    }
+    // Device outputs (both device forms, the synthetic one included): whatever the caller's stream still does with the
+    // buffers of an earlier batch -- a kernel reading its results -- comes before the merge that overwrites them.
+    // (The single-device path has the same ordering through order_after_caller.)
+    CP.ordered = false;
+    if (nq && !from_host && out_ids) {
+        VROD_TRY(set_device(idx->shards[idx->groups[0].members[0]]));
+        if (!CP.caller_ev) HIP_TRY(hipEventCreateWithFlags(&CP.caller_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(CP.caller_ev, (hipStream_t)caller_stream));
+        CP.ordered = true;
     }
     int rc = VROD_OK;
     size_t begun = 0;
@@ -1397,6 +1448,7 @@ static int composite_end(vrod_index* idx, uint64_t* host_ids, float* host_scores
             HIP_TRY(hipMemcpyPeerAsync((char*)D0.recv[c].p + u * M * block, D0.device, idx->groups[u].send[c].p, idx->groups[u].device, M * block, D0.xstream));
     }
     HIP_TRY(hipSetDevice(D0.device));
+    if (CP.ordered) HIP_TRY(hipStreamWaitEvent(D0.xstream, CP.caller_ev, 0));   // the caller's earlier use of the output buffers
     uint64_t* oi = CP.out_ids;
     float* os = CP.out_scores;
     if (host_ids) {
@@ -1527,6 +1579,7 @@ int vrod_index_destroy(vrod_index* idx) {
         }
         (void)hipSetDevice(idx->device);
         if (idx->caller_ev) (void)hipEventDestroy(idx->caller_ev);
+        for (auto& CP : idx->cslot) if (CP.caller_ev) (void)hipEventDestroy(CP.caller_ev);
         idx->out_ids.release(); idx->out_scores.release(); idx->raw_stage.release();
         for (vrod_index* sh : idx->shards) vrod_index_destroy(sh);
         delete idx;
@@ -1545,6 +1598,7 @@ int vrod_index_destroy(vrod_index* idx) {
         P.q_f32.release();
         P.q_planes.release();
         P.dump.release();
+        P.claims.release();
         for (DevBuf* b : {&P.band_idx, &P.band_q, &P.band_q_lp, &P.band_planes, &P.band_small, &P.band_ids, &P.band_scores}) b->release();
         if (P.gexec) (void)hipGraphExecDestroy(P.gexec);
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);

@@ -170,6 +170,9 @@ void Collection::insert(const std::vector<float>& rows, uint32_t dim, const std:
     if (dim != cfg_.dim)
         throw IoError(IoError::InvalidData, "vector dimension " + std::to_string(dim) + " != collection dimension " +
                                                 std::to_string(cfg_.dim));
+    for (const std::string& p : payloads)
+        if (p.find('\n') != std::string::npos || p.find('\r') != std::string::npos)
+            throw IoError(IoError::InvalidData, "a payload must be one line (vr_payloads holds one line per vector)");
     // device first (it validates NaN/Inf), then disk
     if (index_ || cfg_.count > 0) ensure_resident();
     if (!index_) check(create_index(&index_, cfg_.dim, cfg_.dtype, cfg_.metric), "vrod_index_create");
@@ -222,9 +225,12 @@ void Collection::search(const std::vector<float>& queries, uint32_t nq, uint32_t
 
 std::string Collection::payload(uint64_t id) {
     if (!payloads_loaded_) {
+        // only the first `count` lines are payloads of committed rows: lines behind them are orphans of an insert that
+        // never reached its commit point (trim_to_count removes them from the file at the next insert)
         std::ifstream f(join(dir_, "vr_payloads"));
         std::string line;
-        while (std::getline(f, line)) payload_cache_.push_back(line);
+        payload_cache_.clear();
+        while (payload_cache_.size() < cfg_.count && std::getline(f, line)) payload_cache_.push_back(line);
         payloads_loaded_ = true;
     }
     return id < payload_cache_.size() ? payload_cache_[id] : std::string();
