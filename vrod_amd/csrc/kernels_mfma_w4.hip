@@ -34,18 +34,6 @@ namespace vrod {
 // The first K-tile of a corpus tile uses the C = 0 form of the MFMA, so the accumulators are
 // never cleared; the epilogue reads them with v_accvgpr_read.
 // ---------------------------------------------------------------------------------------------
-#ifdef VROD_W4_PROF
-// diagnostic build only (scripts/build_variant.sh prof -DVROD_W4_PROF): shader-clock totals of the filtered 4-wave kernel
-// [0] wave cycles in the kernel  [1] tile epilogues  [2] of which the walk of columns with a hit  [3] wait at the barrier
-// that follows an epilogue  [4] epilogues  [5] epilogues that walked  [6] columns walked  [7] appends  [8] flushes [9] flush cycles
-// [10] counted wait + barrier M  [11] counted wait + barrier E (K-tiles without an epilogue)  [12] K-tiles  [13] phases q0 q1  [14] phases q2 q3
-// (kept in wave-uniform registers while the kernel runs, added to the totals once at its end)
-__device__ unsigned long long g_w4_prof[16];
-__device__ __forceinline__ uint32_t w4_clock() { return (uint32_t)__builtin_readcyclecounter(); }
-#define W4_PROF(...) __VA_ARGS__
-#else
-#define W4_PROF(...)
-#endif
 #ifdef VROD_W4_CLK
 // diagnostic build only (-DVROD_W4_CLK): two stamps per work-group around the scan loop of the filtered launches -- shader
 // clock (s_memtime) and the 100 MHz real-time counter (s_memrealtime) -- summed over work-groups: [0] shader cycles
@@ -211,7 +199,7 @@ __device__ __forceinline__ void w4_spill(const MfmaKernelArgs& a, const float* t
 template <int METRIC>
 __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const float* thr_l, const float* qn2_l, const float* xn_l,
                                                uint32_t tile, uint32_t ql0, uint32_t qb, char* wlog_lds, char* region, int wr, int wc, int lane,
-                                               uint32_t& wlog, uint32_t& wglob W4_PROF(, uint32_t (&pc)[16])) {
+                                               uint32_t& wlog, uint32_t& wglob ) {
     // thr_l / qn2_l: the work-group's per-query values in LDS; xn_l: this lane's 4-row group of the
     // tile's row norms in LDS (m = 0), 16 floats apart per m
     float thr[8], qn2[8];
@@ -251,7 +239,7 @@ __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const fl
         pend |= hl ? 1u << n : 0u;
         colmask |= __any(hl) ? 1u << n : 0u;
     }
-    W4_PROF(const uint32_t pt0 = w4_clock(); pc[4] += 1; if (colmask) pc[5] += 1;)
+    
     if (colmask) {
         const uint32_t log_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)wlog_lds;
         const uint32_t dword = ((tile - a.tile_first) << 9) | (uint32_t)lane;
@@ -265,7 +253,7 @@ __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const fl
                 const bool hl = (pend >> n) & 1u;
                 const unsigned long long hm = __ballot(hl);
                 if (hm == 0ull) return;
-                W4_PROF(pc[6] += 1;)
+                
                 const uint32_t pos = wlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
                 const bool fit = hl && pos < kDumpCap;
                 if (fit) {
@@ -279,11 +267,11 @@ __device__ __forceinline__ void w4_filter_tile(const MfmaKernelArgs& a, const fl
             if (!again) break;
             w4_spill<METRIC>(a, thr_l, qn2_l, wlog_lds, wlog, region, wglob, qb, wr, wc, lane);
             wlog = 0u;
-            W4_PROF(pc[8] += 1;)
+            
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm LDS writes above are not tracked by the compiler
     }
-    W4_PROF(pc[2] += w4_clock() - pt0;)
+    
 }
 
 template <int METRIC>
@@ -492,8 +480,14 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
     w4_mfma_group<MH, NH, ZERO, 5>(FA, FB); DM(3, 0)                                               \
     w4_mfma_group<MH, NH, ZERO, 6>(FA, FB); DM(3, 1)                                               \
     w4_mfma_group<MH, NH, ZERO, 7>(FA, FB);
-#define W4_PHASE(FA, FB, MH, NH, LD, DM)                                                           \
-    if (first) { W4_PHASE_S(FA, FB, MH, NH, true, LD, DM) } else { W4_PHASE_S(FA, FB, MH, NH, false, LD, DM) }
+// a K-tile's four phases with its middle wait + barrier; ZERO: the tile's first K-tile (C = 0 form of the kk = 0 MFMAs)
+#define W4_KTILE(BX, BY, LDQ0, LDQ3, ZERO)                                                         \
+    W4_PHASE_S(FA0, BX, 0, 0, ZERO, LDQ0, W4_DMU0)                                                 \
+    W4_PHASE_S(FA0, BY, 0, 1, ZERO, W4_LDQ1, W4_DMU1)                                              \
+    asm volatile(W4_VMWAIT ::: "memory");                                                          \
+    W4_LOOP_BARRIER();                                                                             \
+    W4_PHASE_S(FA1, BY, 1, 1, ZERO, W4_LDQ2, W4_DMU2)                                              \
+    W4_PHASE_S(FA1, BX, 1, 0, ZERO, LDQ3, W4_DMU3)
 // Ablation builds (timing only, results wrong; scripts/ubench/lib_ab): -DVROD_W4_ABL_NODMA no LDS-DMA piece in the loop
 // (the two K-tiles of the prologue stay in LDS), -DVROD_W4_ABL_NOBAR no barrier in the loop, -DVROD_W4_ABL_NOEPI no tile epilogue
 #ifdef VROD_W4_ABL_NODMA
@@ -503,8 +497,8 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #define W4_DMU3(j, L)
 #define W4_VMWAIT "s_waitcnt lgkmcnt(0)"
 #else
-#define W4_HALF_A(H, I, LOAD) if constexpr (LOAD) w4_dma_load(voa[(I) + 4 * (H)], ua_src); else w4_dma_m0<((I) + 8 * (H)) * 1024>(lds_w + (it & 1u) * kStageBytes);
-#define W4_HALF_B(H, I, LOAD) if constexpr (LOAD) w4_dma_load(vob[(I) + 4 * (H)], ub_src); else w4_dma_m0<32768 + ((I) + 8 * (H)) * 1024>(lds_w + (it & 1u) * kStageBytes);
+#define W4_HALF_A(H, I, LOAD) if constexpr (LOAD) w4_dma_load(voa[(I) + 4 * (H)], ua_src); else w4_dma_m0<((I) + 8 * (H)) * 1024>(lds_wp);
+#define W4_HALF_B(H, I, LOAD) if constexpr (LOAD) w4_dma_load(vob[(I) + 4 * (H)], ub_src); else w4_dma_m0<32768 + ((I) + 8 * (H)) * 1024>(lds_wp);
 #define W4_DMU0(j, L) W4_HALF_A(0, j, L)
 #define W4_DMU1(j, L) W4_HALF_B(0, j, L)
 #define W4_DMU2(j, L) W4_HALF_B(1, j, L)
@@ -521,10 +515,13 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #else
 #define W4_LOOP_BARRIER() VROD_BARRIER()
 #endif
-#define W4_ITER(BX, BY, LDQ0, LDQ3)                                                                \
+// PAR = it & 1, a constant of each of the loop's two copies of this body (the loop starts at it = 0): the LDS addresses of
+// the fragment reads and of the DMA destinations are then loop constants (8 vector adds fewer per K-tile)
+#define W4_ITER(BX, BY, LDQ0, LDQ3, PAR)                                                           \
     {                                                                                              \
-        const char* l = lds + (it & 1) * kStageBytes;                                              \
-        const char* ln = lds + ((it + 1) & 1) * kStageBytes;                                       \
+        const char* l = lds + (PAR) * kStageBytes;                                                 \
+        const char* ln = lds + (1 - (PAR)) * kStageBytes;                                          \
+        const uint32_t lds_wp = lds_w + (PAR) * kStageBytes;                                       \
         const bool first = kt == 0;                                                                \
         /* pacing of the sibling work-groups (see the phased kernel), here in units of K-tiles: with  \
            the staging two K-tiles ahead no work-group ever waits for HBM, so nothing else keeps   \
@@ -553,22 +550,11 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         /* L2: the tile's 256 row norms -> LDS slot of its parity (one 1-KB piece, wave 0) */      \
         if (METRIC == M_L2 && DENSE != 1 && first && wave == 0)                                    \
             w4_dma_piece<0>(lds_addr + kLdsXn2 + (tile & 1u) * 1024u, (uint32_t)lane * 16u, w4_uniform_ptr(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)tile * kBM))); \
-        W4_PROF(const uint32_t pm0 = w4_clock();)                                                  \
-        W4_PHASE(FA0, BX, 0, 0, LDQ0, W4_DMU0)                                                     \
-        W4_PHASE(FA0, BY, 0, 1, W4_LDQ1, W4_DMU1)                                                  \
-        W4_PROF(const uint32_t pm1 = w4_clock();)                                                  \
-        asm volatile(W4_VMWAIT ::: "memory");                                                      \
-        W4_LOOP_BARRIER();                                                                         \
-        W4_PROF(const uint32_t pm2 = w4_clock(); pc[10] += pm2 - pm1; pc[13] += pm1 - pm0; pc[12] += 1;)  \
-        W4_PHASE(FA1, BY, 1, 1, W4_LDQ2, W4_DMU2)                                                  \
-        W4_PHASE(FA1, BX, 1, 0, LDQ3, W4_DMU3)                                                     \
+        if (first) { W4_KTILE(BX, BY, LDQ0, LDQ3, true) } else { W4_KTILE(BX, BY, LDQ0, LDQ3, false) } \
         stage_advance();                                                                           \
-        W4_PROF(const uint32_t pm3 = w4_clock(); pc[14] += pm3 - pm2;)                             \
         const bool last = kt == KT - 1;                                                            \
-        W4_PROF(uint32_t pe0 = 0, pe1 = 0;)                                                        \
         W4_CLK(uint32_t ce1 = 0;)                                                                  \
         if (last) {                                                                                \
-            W4_PROF(pe0 = w4_clock();)                                                             \
             W4_CLK(const uint32_t ce0 = (uint32_t)__builtin_amdgcn_s_memtime();)                   \
             if constexpr (DENSE == 2)                                                              \
                 w4_groupmax_store_tile<METRIC>(a, qn2_l, xn_l + (tile & 1) * 256 + wr * 128 + fg * 4, wc * 128 + fr, \
@@ -577,14 +563,12 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
                 w4_dense_store_tile<METRIC>(a, qn2_l, wc * 128 + fr, tile * kBM + wr * 128 + fg * 4, qb * kBN + wc * 128 + fr); \
             else if (W4_ABL_EPI)                                                                   \
                 w4_filter_tile<METRIC>(a, thr_l, qn2_l, xn_l + (tile & 1) * 256 + wr * 128 + fg * 4,        \
-                                       tile, wc * 128 + fr, qb, wlog_lds, region, wr, wc, lane, wlog, wglob W4_PROF(, pc)); \
-            W4_PROF(pe1 = w4_clock(); pc[1] += pe1 - pe0;)                                         \
+                                       tile, wc * 128 + fr, qb, wlog_lds, region, wr, wc, lane, wlog, wglob ); \
             W4_CLK(ce1 = (uint32_t)__builtin_amdgcn_s_memtime(); cke += ce1 - ce0; ckn += 1;)     \
             kt = 0; ++tile;                                                                        \
         } else ++kt;                                                                               \
         asm volatile(W4_VMWAIT ::: "memory");                                                      \
         W4_LOOP_BARRIER();                                                                         \
-        W4_PROF(if (!DENSE && last) pc[3] += w4_clock() - pe1; else pc[11] += w4_clock() - pm3;)   \
         W4_CLK(if (last) ckb += (uint32_t)__builtin_amdgcn_s_memtime() - ce1;)                     \
         ++it;                                                                                      \
     }
@@ -606,14 +590,14 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         bool pace_on = true;  // (thread 0) false after one pacing timeout: no more pacing in this launch
         // K-tiles to the next pacing point (wave-uniform countdown; pace_every = 0: starts at 0 and wraps, i.e. never) and how many passed
         uint32_t pace_left = a.pace_every ? a.pace_every + 1u : 0u, pace_round = 0u;
-        W4_PROF(uint32_t pc[16] = {}; const uint32_t pk0 = w4_clock();)
+        
         W4_CLK(const uint64_t ck0 = __builtin_amdgcn_s_memtime(); const uint64_t cr0 = __builtin_amdgcn_s_memrealtime(); uint32_t cke = 0, ckb = 0, ckn = 0;)
         while (it < total_it) {
-            W4_ITER(FBx, FBy, W4_LDQ0x, W4_LDQ3x)
+            W4_ITER(FBx, FBy, W4_LDQ0x, W4_LDQ3x, 0)
             if (it >= total_it) break;
-            W4_ITER(FBy, FBx, W4_LDQ0y, W4_LDQ3y)
+            W4_ITER(FBy, FBx, W4_LDQ0y, W4_LDQ3y, 1)
         }
-        W4_PROF(pc[0] = w4_clock() - pk0;)
+        
         W4_CLK(if (!DENSE && tid == 0) {
             const uint64_t ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
             atomicAdd(&g_w4_clk[0], (unsigned long long)(ck1 - ck0)); atomicAdd(&g_w4_clk[1], (unsigned long long)(cr1 - cr0));
@@ -623,7 +607,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #undef W4_LOAD_A1
 #undef W4_LOAD_B1
 #undef W4_PHASE_S
-#undef W4_PHASE
+#undef W4_KTILE
 #undef W4_VMWAIT
 #undef W4_DMU0
 #undef W4_DMU1
@@ -643,17 +627,13 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 #undef W4_LDP_A
 #undef W4_LDP_B
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W4_PROF(const uint32_t pd0 = w4_clock();)
+        
         if constexpr (DENSE == 0) {   // every wave for itself: no barrier
             if (wlog) w4_spill<METRIC>(a, thr_l, qn2_l, wlog_lds, wlog, region, wglob, qb, wr, wc, lane);
             if (wglob) w4_process_region<METRIC>(a, thr_l, qn2_l, region, wglob, qb, wr, wc, lane);
         }
-        W4_PROF(pc[9] = w4_clock() - pd0; pc[7] = wlog;)
-        W4_PROF(if (!DENSE && lane < 16) {
-            uint32_t v = 0;
-            static_for<0, 16>([&](auto ic) { v = lane == decltype(ic)::value ? pc[decltype(ic)::value] : v; });
-            atomicAdd(&g_w4_prof[lane], (unsigned long long)v);
-        })
+        
+        
     }
 }
 
@@ -679,17 +659,6 @@ void launch_mfma_w4(const MfmaKernelArgs& a, int metric, int dense_form, bool sp
 
 }  // namespace vrod
 
-#ifdef VROD_W4_PROF
-extern "C" int vrod_debug_w4_prof(unsigned long long* out16, int reset) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(vrod::g_w4_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(vrod::g_w4_prof), z, sizeof z) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 #ifdef VROD_W4_CLK
 extern "C" int vrod_debug_w4_clk(unsigned long long* out8, int reset) {
