@@ -471,7 +471,10 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 // (Where in a phase the four DMA pieces go does not matter: all behind the fragment reads +0.2 %, all in front of
 // them -1.1 %, alternating 0.0 % -- profiles/r02/mfma_experiments.md section 8.)
 // DM(j, 0): M0 of the phase's j-th piece, DM(j, 1): its load -- a group of MFMAs apart
+// (the explicit lgkmcnt(0) -- s_waitcnt 0xC07F: vmcnt / expcnt untouched -- in front: the phase's fragments were read a
+//  phase ago and have landed; without it hipcc meters them in with four or five counted waits between the first MFMAs)
 #define W4_PHASE_S(FA, FB, MH, NH, ZERO, LD, DM)                                                   \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                            \
     DM(0, 0) w4_mfma_group<MH, NH, ZERO, 0>(FA, FB); LD(0) LD(1) DM(0, 1)                          \
     w4_mfma_group<MH, NH, ZERO, 1>(FA, FB); LD(2) LD(3) DM(1, 0)                                   \
     w4_mfma_group<MH, NH, ZERO, 2>(FA, FB); LD(4) LD(5) DM(1, 1)                                   \
