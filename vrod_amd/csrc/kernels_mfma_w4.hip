@@ -125,6 +125,10 @@ constexpr uint32_t kDumpEntryBytes = 128;                          // 32 fp32: [
 constexpr uint32_t kDumpWaveBytes = (kLdsTotalW4 - kLdsDump) / 4;   // per wave: entries, then one descriptor word each
 constexpr uint32_t kDumpCap = kDumpWaveBytes / (kDumpEntryBytes + 4);
 static_assert(kDumpRegionBytes == kDumpRegionCap * (kDumpEntryBytes + 4), "spill region layout");
+// three words in the slack behind wave 0's log: the range of tiles wave 0 claimed for the work-group {begin, end} and its
+// next own chunk (work stealing, below)
+constexpr int kLdsNext = kLdsDump + kDumpCap * (kDumpEntryBytes + 4);
+static_assert(kLdsNext % 8 == 0 && kLdsNext + 12 <= kLdsDump + (int)kDumpWaveBytes, "the claimed range sits in the slack of wave 0's log");
 static_assert(kDumpCap >= 48 && kDumpCap * (kDumpEntryBytes + 4) <= kDumpWaveBytes && kDumpWaveBytes % 16 == 0, "hit dump layout");
 
 template <int N>
@@ -362,6 +366,90 @@ __device__ __forceinline__ const char* w4_uniform_ptr(const char* p) {
     return (const char*)(((uint64_t)hi << 32) | lo);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Work stealing at the end of a launch.  The 256 work-groups of a launch do not run at one speed: on the same binary the
+// work-groups of the odd XCDs take ~2.5 % longer than those of the even ones, and within an XCD the spread is another
+// +-2..3 % (profiles/r03: per-XCD loop times of the clock-probe build), so with equal static shares the fastest work-group
+// idles for 6-9 % of the launch and the launch lasts as long as its slowest one: 2.7-3.4 % above the mean.  Each strip
+// therefore keeps only the first 15/16 of its tile range as its static share; the rest (its TAIL) is cut into chunks of 2
+// tiles that any work-group of the same query block may claim (sweep: profiles/r03/mfma_experiments.md): the owner takes its own chunks in ascending order behind its
+// static share, a work-group that has run out of its own takes the highest free chunk of another strip.  A claim is one
+// atomic OR on a bit of claims[query block][strip] (zeroed per launch by the launcher), so every (chunk, query block) pair
+// is scanned exactly once whoever takes it; nobody waits for anybody -- a work-group that finds nothing free ends.  The
+// claim is made by wave 0 when the staging cursor enters the LAST tile of the range in hand (a tile = KT K-tiles before
+// the result is needed), published to the other waves through two words of LDS, and the staging pointers jump there
+// without draining the pipeline.  A stolen chunk is scanned without its three sibling query blocks beside it (its corpus
+// tiles are not shared through the XCD's L2): extra HBM reads on at most a few per cent of the rows.
+// ---------------------------------------------------------------------------------------------
+#ifndef VROD_W4_STEAL_CHUNK
+#define VROD_W4_STEAL_CHUNK 2
+#endif
+#ifndef VROD_W4_STEAL_DIV
+#define VROD_W4_STEAL_DIV 16
+#endif
+constexpr uint32_t kStealChunk = VROD_W4_STEAL_CHUNK;     // tiles per claimable chunk
+__host__ __device__ inline uint32_t w4_tail_tiles(uint32_t strip_tiles) {   // tiles of a strip that are handed out dynamically
+    if (strip_tiles < 48u) return 0u;                                       // short launches (first stages, shards of small corpora): static
+    const uint32_t t = strip_tiles / (uint32_t)VROD_W4_STEAL_DIV;
+    return t > 32u * kStealChunk ? 32u * kStealChunk : t;                   // one 32-bit word of claim bits per (query block, strip)
+}
+__device__ __forceinline__ void w4_strip_range(const MfmaKernelArgs& a, uint32_t s, uint32_t& b, uint32_t& e) {
+    b = a.tile_first + (uint32_t)((uint64_t)a.ntiles * s / a.nstrips);
+    e = a.tile_first + (uint32_t)((uint64_t)a.ntiles * (s + 1) / a.nstrips);
+}
+// wave 0: the next range of tiles [cb, ce) of this work-group, or false when nothing is left for its query block
+__device__ __forceinline__ bool w4_claim(const MfmaKernelArgs& a, uint32_t strip, uint32_t qbl, uint32_t& own_next, int lane, uint32_t& cb, uint32_t& ce) {
+    uint32_t* words = a.claims + qbl * a.nstrips;
+    auto chunk = [&](uint32_t s, uint32_t j) {
+        uint32_t b, e;
+        w4_strip_range(a, s, b, e);
+        cb = e - w4_tail_tiles(e - b) + j * kStealChunk;
+        ce = cb + kStealChunk < e ? cb + kStealChunk : e;
+    };
+    {   // own chunks, ascending (a thief may have taken some: it starts from the top)
+        uint32_t b, e;
+        w4_strip_range(a, strip, b, e);
+        const uint32_t cpt = (w4_tail_tiles(e - b) + kStealChunk - 1u) / kStealChunk;
+        while (own_next < cpt) {
+            const uint32_t j = own_next++;
+            uint32_t old = 0u;
+            if (lane == 0) old = atomicOr(&words[strip], 1u << j);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (!((old >> j) & 1u)) { chunk(strip, j); return true; }
+        }
+    }
+    // steal: lane l looks at strip + 1 + l (one round trip for 64 strips); the first strip with a free chunk gives its highest one
+    for (uint32_t base = 1u; base < a.nstrips; base += 64u) {
+        const uint32_t v = base + (uint32_t)lane;
+        const uint32_t s = (strip + v) % a.nstrips;
+        uint32_t free_bits = 0u;
+        if (v < a.nstrips) {
+            uint32_t b, e;
+            w4_strip_range(a, s, b, e);
+            const uint32_t cpt = (w4_tail_tiles(e - b) + kStealChunk - 1u) / kStealChunk;
+            const uint32_t w = __hip_atomic_load(&words[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            free_bits = ~w & (cpt >= 32u ? 0xFFFFFFFFu : ((1u << cpt) - 1u));
+        }
+        unsigned long long cand = __ballot(free_bits != 0u);
+        while (cand) {
+            const int L = __builtin_ctzll(cand);
+            uint32_t ok = 0u, jj = 0u;
+            if (lane == L) {
+                jj = 31u - (uint32_t)__builtin_clz(free_bits);
+                const uint32_t old = atomicOr(&words[s], 1u << jj);
+                ok = ((old >> jj) & 1u) ? 0u : 1u;
+                free_bits &= ~(old | (1u << jj));
+            }
+            if (__builtin_amdgcn_readlane(ok, L)) {
+                chunk(__builtin_amdgcn_readlane(s, L), __builtin_amdgcn_readlane(jj, L));
+                return true;
+            }
+            cand = __ballot(free_bits != 0u);
+        }
+    }
+    return false;
+}
+
 // DENSE: 0 = filtered launch, 1 = sample pass writing every score, 2 = sample pass writing group bests (one kernel per
 // form: with both sample epilogues in one function hipcc ran out of VGPRs and went into the accumulator file).
 template <int METRIC, int DENSE, bool SPLIT>
@@ -394,7 +482,10 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
     const uint32_t b_frag0 = 32768u + ((wc * 16 + (fr >> 3)) << 10) + (r7 << 7);
     const uint32_t c_off0 = ((0 * 4 + fg) ^ r7) << 4, c_off1 = ((1 * 4 + fg) ^ r7) << 4;
     const uint32_t piece_stride_a = 8u * lda_bytes, piece_stride_b = 8u * a.ld_bytes;   // 8 rows; 31 pieces fit 32 bits
-    const uint32_t total_it = (t1 - t0) * KT;
+    // The strip's static share [t0, t1s); behind it come claimed chunks (work stealing: filtered launches of long strips,
+    // K extents of at least three K-tiles -- the MFMAs then always find the tile they move on to in the staging cursor).
+    const uint32_t t1s = (DENSE == 0 && a.claims != nullptr && KT >= 3u) ? t1 - w4_tail_tiles(t1 - t0) : t1;
+    uint32_t total_it = 0xFFFFFFFFu;   // K-tiles of this work-group: known once the staging cursor has run out of tiles
 
     // ONE query block per work-group: a loop over query blocks here would re-enter the prologue with the
     // accumulator file live in hipcc's eyes (it parks kernel-entry values in AGPRs up to the first MFMA);
@@ -404,6 +495,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         float* thr_l = reinterpret_cast<float*>(lds + kLdsThr);
         float* qn2_l = reinterpret_cast<float*>(lds + kLdsQn2);
         const float* xn_l = reinterpret_cast<const float*>(lds + kLdsXn2);
+        if (tid == 0) lds_zero3(reinterpret_cast<uint32_t*>(lds + kLdsNext));   // claimed range: none; next own chunk: 0
         thr_l[tid] = DENSE ? 0.0f : a.thr[qb * kBN + tid];
         qn2_l[tid] = METRIC == M_L2 ? a.qnorm2[qb * kBN + tid] : 0.0f;
         // (published by the prologue's __syncthreads)
@@ -422,6 +514,9 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         }
         const uint32_t lds_w = __builtin_amdgcn_readfirstlane(lds_addr + p0 * 1024u);
         uint32_t st_kt = 0, st_tile = t0, a_kt = 0;   // a_kt: K-tile of the corpus row ua_src points at
+        uint32_t st_end = t1s;                        // end of the range of tiles the staging cursor walks
+        bool pace_on = true;                          // (thread 0) false after one pacing timeout / behind the static share: no more pacing in this launch
+        const uint32_t next_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + kLdsNext);
         // unit A_mh / B_nh = the 16 pieces (8 rows x 128 B each) of rows [h*64, h*64+64) of both
         // 128-row halves; this wave moves 4 of them: idx = wave*4 + i -> piece (idx>>3)*16 + (idx&7) + h*8
         // unit A_mh / B_nh = the 16 pieces (8 rows x 128 B each) of rows [h*64, h*64+64) of both 128-row halves
@@ -431,7 +526,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         // next K-tile of the same tile -- is two scalar adds behind one compare; the tile boundary is a wave-uniform branch.
         // (The bases are SGPR pairs now: with per-lane pointers this had to be written with selects, hipcc moved branchy
         // pointer updates into a scratch array.)
-        auto stage_advance = [&]() {
+        auto stage_advance = [&](int32_t it_adv /* the iteration this advance belongs to; -2, -1 in the prologue */) {
             if (st_kt + 1 < KT) {
                 // SPLIT: K-tiles 3j, 3j+1, 3j+2 read corpus K-tile 2j, 2j, 2j+1 ([hi_j | lo_j] interleaved: the
                 // hi plane is staged twice in a row, the second time from L2); a_kt = corpus K-tile
@@ -440,13 +535,37 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
                 ua_src += hold ? 0 : 128;
                 ub_src += 128;
                 ++st_kt;
-            } else if (st_tile + 1 < t1) {
-                const int64_t a_back = SPLIT ? (int64_t)a_kt * 128 : (int64_t)(KT - 1) * 128;
-                ua_src += (int64_t)kBM * lda_bytes - a_back;
-                ub_src -= (int64_t)(KT - 1) * 128;
-                if constexpr (SPLIT) a_kt = 0u;
-                st_kt = 0u;
-                ++st_tile;
+            } else {
+                // tile boundary: the next tile of the range in hand, or -- the range is through -- the first of the range
+                // wave 0 claimed a tile ago ({begin, end} in LDS; begin = end: none), or nothing: the cursor stays (the last
+                // K-tile is re-staged, never read) and the loop's end is known
+                uint32_t nt = st_tile + 1u;
+                bool have = nt < st_end;
+                if (DENSE == 0 && !have) {
+                    const uint2 nx = *reinterpret_cast<const uint2*>(lds + kLdsNext);
+                    if (nx.y > nx.x) { nt = nx.x; st_end = nx.y; have = true; pace_on = false; }   // (behind its static share a work-group no longer paces)
+                }
+                if (have) {
+                    const int64_t a_back = SPLIT ? (int64_t)a_kt * 128 : (int64_t)(KT - 1) * 128;
+                    ua_src += (int64_t)(int32_t)(nt - st_tile) * ((int64_t)kBM * lda_bytes) - a_back;
+                    ub_src -= (int64_t)(KT - 1) * 128;
+                    if constexpr (SPLIT) a_kt = 0u;
+                    st_kt = 0u;
+                    st_tile = nt;
+                    // The cursor has entered the LAST tile of the range in hand: wave 0 claims the range that follows and leaves
+                    // it in LDS for everybody's advance out of this tile, KT K-tiles from now (their barriers order the write
+                    // before the reads).  The third word is wave 0's own bookkeeping: its next own chunk.
+                    if (DENSE == 0 && nt + 1u == st_end && wave == 0 && t1s != t1) {
+                        uint32_t cb = 0u, ce = 0u;
+                        uint32_t own_next = *reinterpret_cast<const uint32_t*>(lds + kLdsNext + 8);
+                        (void)w4_claim(a, strip, qb0, own_next, lane, cb, ce);
+                        if (lane == 0)
+                            asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %0, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                                         :: "v"(next_addr), "v"(((uint64_t)ce << 32) | cb), "v"(own_next) : "memory");
+                    }
+                } else if (total_it == 0xFFFFFFFFu) {
+                    total_it = (uint32_t)(it_adv + 3);   // the cursor stands at K-tile it_adv + 2, the last one
+                }
             }
             // (behind the join hipcc would keep the two bases in VGPRs: an "s" asm operand then prints as v[..])
             ua_src = w4_uniform_ptr(ua_src);
@@ -458,9 +577,9 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
                          W4_STAGE_A(B, 0, 3) W4_STAGE_B(B, 0, 3) W4_STAGE_A(B, 1, 0) W4_STAGE_B(B, 1, 0) W4_STAGE_A(B, 1, 1) W4_STAGE_B(B, 1, 1)   \
                          W4_STAGE_A(B, 1, 2) W4_STAGE_B(B, 1, 2) W4_STAGE_A(B, 1, 3) W4_STAGE_B(B, 1, 3)
         W4_STAGE_UNIT(0u)
-        stage_advance();
+        stage_advance(-2);
         W4_STAGE_UNIT(1u)
-        stage_advance();
+        stage_advance(-1);
 #undef W4_STAGE_UNIT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -554,7 +673,7 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
         if (METRIC == M_L2 && DENSE != 1 && first && wave == 0)                                    \
             w4_dma_piece<0>(lds_addr + kLdsXn2 + (tile & 1u) * 1024u, (uint32_t)lane * 16u, w4_uniform_ptr(reinterpret_cast<const char*>(a.xnorm2 + (uint64_t)tile * kBM))); \
         if (first) { W4_KTILE(BX, BY, LDQ0, LDQ3, true) } else { W4_KTILE(BX, BY, LDQ0, LDQ3, false) } \
-        stage_advance();                                                                           \
+        stage_advance((int32_t)it);                                                                \
         const bool last = kt == KT - 1;                                                            \
         W4_CLK(uint32_t ce1 = 0;)                                                                  \
         if (last) {                                                                                \
@@ -568,7 +687,8 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
                 w4_filter_tile<METRIC>(a, thr_l, qn2_l, xn_l + (tile & 1) * 256 + wr * 128 + fg * 4,        \
                                        tile, wc * 128 + fr, qb, wlog_lds, region, wr, wc, lane, wlog, wglob ); \
             W4_CLK(ce1 = (uint32_t)__builtin_amdgcn_s_memtime(); cke += ce1 - ce0; ckn += 1;)     \
-            kt = 0; ++tile;                                                                        \
+            kt = 0;                                                                                \
+            tile = KT >= 3u ? st_tile : tile + 1u;   /* the cursor is two K-tiles ahead: in the tile the MFMAs move on to */ \
         } else ++kt;                                                                               \
         asm volatile(W4_VMWAIT ::: "memory");                                                      \
         W4_LOOP_BARRIER();                                                                         \
@@ -590,7 +710,6 @@ __global__ __launch_bounds__(256) void scan_mfma_w4_kernel(const MfmaKernelArgs 
 
         uint32_t it = 0, kt = 0, tile = t0;
         uint32_t wlog = 0u, wglob = 0u;   // entries in this wave's hit log / in its spill region (wave-uniform)
-        bool pace_on = true;  // (thread 0) false after one pacing timeout: no more pacing in this launch
         // K-tiles to the next pacing point (wave-uniform countdown; pace_every = 0: starts at 0 and wraps, i.e. never) and how many passed
         uint32_t pace_left = a.pace_every ? a.pace_every + 1u : 0u, pace_round = 0u;
         
