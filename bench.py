@@ -535,7 +535,7 @@ def main():
         if wl["bound"] == "mfma":
             roofline["by_kernel"] = by_kernel
         rows_per_handle = (n_total + world - 1) // world
-        early_env = os.environ.get("VROD_EARLY_SAMPLE")
+        early_env = os.environ.get("VROD_DEBUG_EARLY_SAMPLE")
         if wl["bound"] == "mfma" and (early_env not in (None, "0") or (early_env is None and rows_per_handle <= 6_000_000)):
             # (vrod_index.hip: up to 6M rows per handle the next batch's sample pass runs beside this batch's last stage)
             roofline["overlap"] = ("sample pass of the next batch runs beside this batch's last stage: per-launch times "

@@ -29,6 +29,15 @@
  * better), L2 scores are squared Euclidean distances (lower is better); results are
  * best-first, ties broken by smaller id; unfilled slots (k > count) are
  * (VROD_ID_NONE, NaN).  Results are bit-identical to the CPU oracle (oracle/).
+ *
+ * Environment (read once per process; everything else the library reads is
+ * VROD_DEBUG_*: A/B switches of the build's own experiments):
+ *   VROD_F32_SPLIT = 0 | 1   fp32 handles: never | always scan batches through the
+ *                            bf16 [hi | lo] planes (default: while the planes fit)
+ *   VROD_RCCL = 0            multi-device handles exchange their lists by peer copies
+ *                            instead of the RCCL all-gather
+ *   VROD_RCCL_LIB = path     the RCCL library to bind (nothing else is tried; a path
+ *                            that does not load means peer copies, said once on stderr)
  */
 #ifndef VROD_H
 #define VROD_H

@@ -1,7 +1,7 @@
 """The sample pass of the batched scan has two forms on the 2 x 2 4-wave kernel: every score of the sample rows
 written out (threshold = exact j-th best), or one score per group of 32 rows (threshold = j-th best of the group
 bests: a valid lower bound, 1/32 of the writes; default where the groups outnumber j by 8x).  Both must give the
-oracle's bits; VROD_SAMPLE_GROUPED is read once per process, so each form runs in a child process.
+oracle's bits; VROD_DEBUG_SAMPLE_GROUPED is read once per process, so each form runs in a child process.
 Parity unpinned by the reference (vRod holds no scan): the oracle is build-authored."""
 import os
 import subprocess
@@ -43,7 +43,7 @@ print("sample form ok", n_cases)
 @pytest.mark.gpu
 @pytest.mark.parametrize("grouped", ["1", "0"])
 def test_both_sample_forms_match_the_oracle(grouped):
-    env = dict(os.environ, VROD_SAMPLE_GROUPED=grouped)
+    env = dict(os.environ, VROD_DEBUG_SAMPLE_GROUPED=grouped)
     r = subprocess.run([sys.executable, "-c", CHILD.replace('ROOT_PLACEHOLDER', repr(ROOT))], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "sample form ok 4" in r.stdout
