@@ -83,7 +83,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
             // work stealing (kernels_mfma_w4.hip): the claim bits of this launch start at zero.  VROD_DEBUG_W4_STEAL=0: static shares (A/B runs)
             static const bool steal_on = [] { const char* e = getenv("VROD_DEBUG_W4_STEAL"); return !e || e[0] != '0'; }();
             a.claims = (form == 0 && steal_on && h.claims && (size_t)a.nqb * a.nstrips <= kMfmaClaimWords) ? h.claims : nullptr;
-            if (a.claims) (void)hipMemsetAsync(a.claims, 0, (size_t)a.nqb * a.nstrips * sizeof(uint32_t), s);
+            if (a.claims && (qb_base > 0 || !h.claims_is_zero)) (void)hipMemsetAsync(a.claims, 0, (size_t)a.nqb * a.nstrips * sizeof(uint32_t), s);
             launch_mfma_w4(a, h.metric, form, split, grid, s, first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr);
         }
         return;

@@ -83,6 +83,11 @@ struct DevBuf {
 
 static inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
+// a search slot's block of device words: 64 scalars, then one region of sibling-pacing counters and one of work-stealing
+// claim bits per scan launch of the search (8 of each; a search with more launches reuses them behind a memset)
+constexpr uint32_t kPaceRegions = 8, kPaceWords = 192, kClaimWords = (uint32_t)kMfmaClaimWords;
+constexpr size_t kSlotFlagBytes = (64 + kPaceRegions * (kPaceWords + kClaimWords)) * 4;
+
 // ------------------------------------------------------------------ one search in flight
 // A search is ENQUEUED (every launch up to the D2H of its status block) and later COMPLETED (wait
 // for that copy, read the certificate's verdicts, run the exact path for the rare failures).  Two
@@ -103,10 +108,9 @@ struct Pending {
     // re-score, certificate, read-back) can run beside the head -- and, on the stream path, the
     // scan -- of search s+1.  Only the corpus (read-only during a search) is shared.
     hipStream_t stream = nullptr;
-    uint32_t* flags = nullptr;     // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits, [64..] pacing counters
+    uint32_t* flags = nullptr;     // [0] bad-value flag, [1] max query norm^2 bits, [2] max err bits, [64..] pacing counters, then claim bits (kSlotFlagBytes)
     DevBuf q_raw, q_lp, scores, keys_a, keys_b, lists, small, hist, cand_rows, cand_fast, cand_canon;
     DevBuf q_f32;                  // prepared queries (the exact path re-reads them)
-    DevBuf claims;                 // MFMA path: claim bits of the 4-wave kernel's work stealing (kMfmaClaimWords words, zeroed per launch by the launcher)
     DevBuf dump;                   // MFMA path: spill regions of the 4-wave kernel's hit logs (scratch, mfma_dump_bytes)
     DevBuf q_planes;               // split pass: [nq_pad][3 * ldp] bf16, [hi_j | lo_j | hi_j] per K-tile j
     // band pass (second chance of the queries whose certificate failed, search_complete)
@@ -582,10 +586,12 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     qi.zero_words = nullptr;
     qi.n_zero_words = 0;
     // pacing counters: 8 regions of 192 words behind the scalars, one per scan launch of this search
-    constexpr uint32_t kPaceRegions = 8, kPaceWords = 192;
+    // and behind them the claim bits of the 4-wave kernel's work stealing, one region per scan launch likewise: both are
+    // zeroed by the launch that prepares the queries (no memset node per scan launch)
     uint32_t* pace_base = P.flags + 64;
+    uint32_t* claim_base = pace_base + kPaceRegions * kPaceWords;
     qi.zero_words2 = mfma ? pace_base : nullptr;
-    qi.n_zero_words2 = kPaceRegions * kPaceWords;
+    qi.n_zero_words2 = kPaceRegions * (kPaceWords + kClaimWords);
     const size_t hist_words = 8 * 4096 + 8;   // stream path: [8][<=4096] bin counters + 8 key counters
     if (path == VROD_PATH_STREAM) {
         VROD_TRY(P.hist.ensure(hist_words * 4));
@@ -681,8 +687,6 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nq_pad; a.nq = nq; a.metric = idx->metric;
         VROD_TRY(P.dump.ensure(mfma_dump_bytes(idx->num_cus)));
         a.dump = P.dump.p;
-        VROD_TRY(P.claims.ensure(kMfmaClaimWords * 4));
-        a.claims = P.claims.as<uint32_t>();
         int scan_dtype = idx->dtype;
         if (split) {
             // planes of the rows added since the last batched search, and of this batch's queries
@@ -739,6 +743,8 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
                 a.row_begin = (uint32_t)lo; a.row_end = (uint32_t)end;
                 a.pace = pace_base + (pace_launch % kPaceRegions) * kPaceWords;
                 a.pace_is_zero = pace_launch < kPaceRegions;   // later launches reuse a region: memset
+                a.claims = claim_base + (pace_launch % kPaceRegions) * kClaimWords;
+                a.claims_is_zero = a.pace_is_zero;
                 ++pace_launch;
                 size_t e0, e1;
                 tm.arm(e0, e1);
@@ -913,8 +919,6 @@ static int band_pass(vrod_index* idx, Pending& P, std::vector<uint32_t>& failed,
     a.lists = d_lists; a.counts = d_counts; a.cap = cap; a.ld = idx->ld; a.nq_pad = nf_pad; a.nq = nf; a.metric = idx->metric;
     VROD_TRY(P.dump.ensure(mfma_dump_bytes(idx->num_cus)));
     a.dump = P.dump.p;
-    VROD_TRY(P.claims.ensure(kMfmaClaimWords * 4));
-    a.claims = P.claims.as<uint32_t>();
     int scan_dtype = idx->dtype;
     if (P.split) {
         VROD_TRY(P.band_planes.ensure((size_t)nf_pad * 3 * idx->ldp * 2));
@@ -923,14 +927,16 @@ static int band_pass(vrod_index* idx, Pending& P, std::vector<uint32_t>& failed,
         a.ld = 3 * idx->ldp; a.lda_bytes = 2 * idx->ldp * 2; a.a_wrap = 1;
         scan_dtype = VROD_DTYPE_BF16;
     }
-    constexpr uint32_t kPaceRegions = 8, kPaceWords = 192;
     uint32_t* pace_base = P.flags + 64;
+    uint32_t* claim_base = pace_base + kPaceRegions * kPaceWords;
     const double row_bytes_alg = (double)idx->ld * idx->esize;
     for (uint64_t lo = 0; lo < N;) {
         const uint64_t end = std::min<uint64_t>(N, lo / kRowTile * kRowTile + (1ull << 24));
         a.row_begin = (uint32_t)lo; a.row_end = (uint32_t)end;
         a.pace = pace_base + (P.pace_launches % kPaceRegions) * kPaceWords;
         a.pace_is_zero = false;   // the regions were used by the search's own launches
+        a.claims = claim_base + (P.pace_launches % kPaceRegions) * kClaimWords;
+        a.claims_is_zero = false;
         ++P.pace_launches;
         size_t e0, e1;
         tm.arm(e0, e1);
@@ -1549,8 +1555,8 @@ int vrod_index_create(vrod_index** out, uint32_t dim, int dtype, int metric, con
         idx->max_xn2_bits = idx->flags + 8;
         for (Pending& P : idx->slot) {
             if (hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipStreamCreate failed"); break; }
-            if (hipMalloc((void**)&P.flags, 8192) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
-            if (hipMemset(P.flags, 0, 8192) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
+            if (hipMalloc((void**)&P.flags, kSlotFlagBytes) != hipSuccess) { rc = fail(VROD_ERR_OUT_OF_MEMORY, "hipMalloc failed"); break; }
+            if (hipMemset(P.flags, 0, kSlotFlagBytes) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipMemset failed"); break; }
             if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&P.scans_done, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&P.mid_done, hipEventDisableTiming) != hipSuccess) { rc = fail(VROD_ERR_HIP, "hipEventCreate failed"); break; }
@@ -1598,7 +1604,6 @@ int vrod_index_destroy(vrod_index* idx) {
         P.q_f32.release();
         P.q_planes.release();
         P.dump.release();
-        P.claims.release();
         for (DevBuf* b : {&P.band_idx, &P.band_q, &P.band_q_lp, &P.band_planes, &P.band_small, &P.band_ids, &P.band_scores}) b->release();
         if (P.gexec) (void)hipGraphExecDestroy(P.gexec);
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);

@@ -186,11 +186,12 @@ struct MfmaScanArgs {
     bool dense_grouped;     // sample pass, grouped form: dense_out is [nq_pad][dense_ld] with ONE score per group of
                             // mfma_dense_group_rows() consecutive rows (the group's best), dense_ld = groups per query
     void* dump;             // mfma_dump_bytes(num_cus) bytes of scratch: where the 4-wave kernel spills full hit logs (filtered launches)
-    uint32_t* claims;       // kMfmaClaimWords words of scratch (the launcher zeroes them per launch): work stealing of the 4-wave kernel; null: off
+    uint32_t* claims;       // kMfmaClaimWords words: claim bits of the 4-wave kernel's work stealing for THIS launch; null: off
+    bool claims_is_zero;    // the caller already cleared them (else the launcher issues a memset)
 };
 void launch_scan_mfma(const MfmaScanArgs& a, int dtype, int num_cus, hipStream_t s);
 size_t mfma_dump_bytes(int num_cus);
-constexpr size_t kMfmaClaimWords = 1024;   // >= query blocks per launch x strips (8 x work-groups per XCD in all)
+constexpr size_t kMfmaClaimWords = 256;    // >= query blocks per launch x strips (8 x work-groups per XCD in all)
 // Rows per group of the grouped sample form for this launch (32), or 0 when the kernel that would take it only
 // writes every score (dense_grouped must then stay false).
 uint32_t mfma_dense_group_rows(const MfmaScanArgs& a, int dtype);
