@@ -40,6 +40,7 @@ pub struct vrod_search_stats {
     pub band_queries: u32,
     pub sample_ms: f32,
     pub exchange: u32,
+    pub overlap_ms: f32,
 }
 
 extern "C" {
@@ -74,6 +75,8 @@ extern "C" {
     pub fn vrod_index_set_path(idx: *mut vrod_index, path: c_int) -> c_int;
     pub fn vrod_index_set_profiling(idx: *mut vrod_index, on: c_int) -> c_int;
     pub fn vrod_index_last_stats(idx: *const vrod_index, out: *mut vrod_search_stats) -> c_int;
+    pub fn vrod_index_shard_stats(idx: *const vrod_index, shard: u32, out_device: *mut c_int,
+                                  out: *mut vrod_search_stats) -> c_int;
     pub fn vrod_last_error() -> *const c_char;
     pub fn vrod_version() -> *const c_char;
     pub fn vrod_synth_rows_device(device: c_int, seed: u64, first_row: u64, n: u64, dim: u32,

@@ -92,6 +92,10 @@ typedef struct {
                                  * again by the first filtered launch); 0 when the search had none */
     uint32_t exchange;          /* multi-device handle: how the per-shard lists reached the merge --
                                  * 0 none (single device), 1 RCCL all-gather, 2 peer copies (VROD_RCCL=0) */
+    float overlap_ms;           /* of scan_ms: how long this search's sample-pass launch and the PREVIOUS search's last scan
+                                 * launch were both in flight (pipelined searches over up to 6M rows put the two side by
+                                 * side; each launch's own time then includes waiting for compute units).  The sum of
+                                 * scan_ms - overlap_ms over a run = the time at least one scan launch was in flight */
 } vrod_search_stats;
 
 /* --- lifecycle ------------------------------------------------------------- */
@@ -181,6 +185,10 @@ int vrod_merge_topk_packed_device(int device, int metric, const void *d_packed, 
 int vrod_index_set_path(vrod_index *idx, int path);      /* VROD_PATH_* (default AUTO) */
 int vrod_index_set_profiling(vrod_index *idx, int on);   /* 1: scan_ms (events attached to the scan dispatches), 2: + total_ms (stream markers) */
 int vrod_index_last_stats(const vrod_index *idx, vrod_search_stats *out);
+/* The same counters for ONE shard of the most recently completed search (a multi-device handle has a shard per
+ * entry of device_ids, in that order; a single-device handle has shard 0 = itself), and the device the shard
+ * lives on (out_device may be NULL): what each GPU of such a handle spent.  shard out of range: INVALID_ARG. */
+int vrod_index_shard_stats(const vrod_index *idx, uint32_t shard, int *out_device, vrod_search_stats *out);
 const char *vrod_last_error(void);                       /* thread-local text */
 const char *vrod_version(void);
 

@@ -91,3 +91,5 @@ def test_bench_inprocess_two_shards_one_handle(rccl):
     assert out["n_gpus"] == 2
     assert_multi_gpu_fields(out)
     assert ("RCCL all-gather" in out["config"]["parallelism"]) == (rccl == "1")
+    # what each shard's device spent (vrod_index_shard_stats)
+    assert [d["shard"] for d in out["per_device"]] == [0, 1] and all(d["device"] == 0 and d["scan_ms_per_step"] > 0 for d in out["per_device"])

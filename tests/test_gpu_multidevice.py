@@ -140,6 +140,11 @@ def test_synthetic_add_small_corpus_and_device_pointers(va, oracle):
         ix.search_begin_device(dq, k, di, ds)       # the pipelined form, one batch
         ix.search_end()
         assert np.array_equal(di.cpu().numpy().view(np.uint64), oi) and np.array_equal(bits(ds.cpu().numpy()), bits(osc))
+        per = [ix.shard_stats(g) for g in range(3)]  # per-shard counters of that search
+        assert all(p["device"] == 0 and p["nq"] in (0, 4) for p in per) and per[0]["nq"] == 4 and per[0]["scan_launches"] >= 1
+        assert sum(p["scan_launches"] for p in per) == ix.last_stats()["scan_launches"]
+        with pytest.raises(va.VrodError):
+            ix.shard_stats(3)
     big_k = 1200                                    # k > count: unfilled slots (ID_NONE, NaN) survive the merge
     with va.Index(dim, "f32", "l2", devices=[0, 0]) as ix:
         ix.add(raw)

@@ -176,3 +176,31 @@ def test_more_query_blocks_than_work_group_slots(va, oracle):
         assert ix.last_stats()["path"] == 2
     oi, osc = oracle.search(raw, rq, k, 1, 0)
     assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))
+
+
+def test_overlap_of_two_scan_launches_is_reported_once(va):
+    """Pipelined staged MFMA searches over a shard-sized corpus put the next batch's sample launch beside this batch's
+    last stage; vrod_search_stats.overlap_ms is how long both were in flight, so that scan_ms - overlap_ms is the time
+    at least one scan launch ran (what bench.py's roofline divides by).  Synchronous searches overlap nothing."""
+    import torch
+    dev = torch.device("cuda", 0)
+    nq, k = 512, 10
+    with va.Index(128, "bf16", "cosine") as ix:
+        ix.add_synthetic(1, 0, 600000)
+        ix.set_profiling(True)
+        outs = [(torch.empty((nq, k), dtype=torch.int64, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev)) for _ in range(2)]
+        stats = []
+        ix.search_begin_synthetic_device(2, 0, nq, k, *outs[0])
+        for s in range(6):
+            if s + 1 < 6:
+                ix.search_begin_synthetic_device(2, (s + 1) * nq, nq, k, *outs[(s + 1) % 2])
+            ix.search_end()
+            stats.append(ix.last_stats())
+        ix.search_synthetic_device(2, 0, nq, k, *outs[0])
+        sync = ix.last_stats()
+    assert all(st["path"] == 2 and st["scan_launches"] >= 3 and st["sample_ms"] > 0 for st in stats), stats
+    assert stats[0]["overlap_ms"] == 0                      # nothing in front of the first search
+    for st in stats[1:]:
+        assert 0 <= st["overlap_ms"] <= st["sample_ms"] + 1e-3 and st["overlap_ms"] < st["scan_ms"], st
+    assert any(st["overlap_ms"] > 0 for st in stats[1:]), stats     # the default order at this size is the overlapping one
+    assert sync["overlap_ms"] == 0 and sync["sample_ms"] > 0

@@ -19,7 +19,7 @@ SYMBOLS = [
     "vrod_index_get_rows", "vrod_search", "vrod_search_device", "vrod_search_synthetic_device",
     "vrod_search_begin_device", "vrod_search_begin_synthetic_device", "vrod_search_end", "vrod_search_pending",
     "vrod_merge_topk_device", "vrod_merge_topk_packed_device", "vrod_index_set_path", "vrod_index_set_profiling",
-    "vrod_index_last_stats", "vrod_last_error", "vrod_version", "vrod_synth_rows_device",
+    "vrod_index_last_stats", "vrod_index_shard_stats", "vrod_last_error", "vrod_version", "vrod_synth_rows_device",
 ]
 
 
@@ -37,6 +37,7 @@ class SearchStats(C.Structure):
         ("scan_bytes", C.c_double), ("scan_flops", C.c_double),
         ("max_fast_err", C.c_float), ("eps_bound", C.c_float),
         ("split_pass", C.c_uint32), ("band_queries", C.c_uint32), ("sample_ms", C.c_float), ("exchange", C.c_uint32),
+        ("overlap_ms", C.c_float),
     ]
 
     def as_dict(self):
@@ -83,6 +84,7 @@ def load() -> C.CDLL:
     L.vrod_index_set_path.argtypes = [vp, i32]
     L.vrod_index_set_profiling.argtypes = [vp, i32]
     L.vrod_index_last_stats.argtypes = [vp, C.POINTER(SearchStats)]
+    L.vrod_index_shard_stats.argtypes = [vp, u32, C.POINTER(i32), C.POINTER(SearchStats)]
     L.vrod_synth_rows_device.argtypes = [i32, u64, u64, u64, u32, vp, vp]
     for name in SYMBOLS:
         getattr(L, name).restype = i32

@@ -127,6 +127,9 @@ struct Pending {
     size_t ev_used = 0, t0 = 0, t1 = 0;
     std::vector<std::pair<size_t, size_t>> scan_pairs;
     int sample_pair = -1;          // index in scan_pairs of the sample-pass launch (-1: none)
+    int tail_pair = -1;            // index in scan_pairs of the last filtered launch of a staged MFMA search: timed by idx->tail_ev[seq & 3]
+    uint32_t seq = 0;              // number of this search on its handle (n_begun when it was enqueued)
+    bool early_sample = false;     // its sample pass was ordered in front of the previous search's last stage
     vrod_search_stats st{};
 
     // hipGraph replay of small, launch-bound searches (search_enqueue): the launches of a search
@@ -179,6 +182,10 @@ struct vrod_index {
     DevBuf raw_stage, nrm_ws, out_ids, out_scores;
     uint32_t* flags = nullptr;  // [0] bad-value flag of the insert path; [8] max squared row norm
     Pending slot[2];
+    // start / stop of the last filtered scan launch of the four most recent searches (Timer::arm_tail): the next search's
+    // sample launch may overlap it, and measures by how much when it completes
+    struct TailEv { hipEvent_t start = nullptr, stop = nullptr; bool armed = false; };
+    TailEv tail_ev[4];
     uint32_t n_begun = 0, n_ended = 0;   // searches enqueued / completed: slot = counter & 1
     hipEvent_t caller_ev = nullptr;      // orders the caller's stream before ours
 
@@ -363,6 +370,40 @@ struct Timer {
         if (idx->profiling && a < P.ev_used && b < P.ev_used) (void)hipEventElapsedTime(&m, P.ev[a], P.ev[b]);
         return m;
     }
+    // The LAST filtered launch of a staged MFMA search is timed by events of the handle's ring instead (tail_ev[seq & 3]):
+    // the next search's sample pass may run beside it, and that search wants both intervals when it is completed --
+    // by then this slot's own events belong to the search after it.
+    void arm_tail() {
+        if (!idx->profiling) return;
+        vrod_index::TailEv& T = idx->tail_ev[P.seq & 3];
+        if (!T.start && hipEventCreate(&T.start) != hipSuccess) return;
+        if (!T.stop && hipEventCreate(&T.stop) != hipSuccess) return;
+        g_launch_events.start = T.start;
+        g_launch_events.stop = T.stop;
+        T.armed = true;
+        P.tail_pair = (int)P.scan_pairs.size();
+    }
+    float pair_ms(size_t i) {
+        if ((int)i == P.tail_pair) {
+            const vrod_index::TailEv& T = idx->tail_ev[P.seq & 3];
+            float m = 0.f;
+            if (idx->profiling && T.armed) (void)hipEventElapsedTime(&m, T.start, T.stop);
+            return m;
+        }
+        return ms(P.scan_pairs[i].first, P.scan_pairs[i].second);
+    }
+    // ms during which this search's sample launch and the previous search's last filtered launch were BOTH in flight
+    float sample_overlap_ms() {
+        if (!idx->profiling || P.sample_pair < 0 || !P.early_sample || P.seq == 0) return 0.f;
+        const vrod_index::TailEv& T = idx->tail_ev[(P.seq - 1) & 3];
+        const size_t a = P.scan_pairs[P.sample_pair].first, b = P.scan_pairs[P.sample_pair].second;
+        if (!T.armed || a >= P.ev_used || b >= P.ev_used) return 0.f;
+        float tail_len = 0.f, s0 = 0.f, s1 = 0.f;   // everything relative to the start of that launch
+        if (hipEventElapsedTime(&tail_len, T.start, T.stop) != hipSuccess) return 0.f;
+        if (hipEventElapsedTime(&s0, T.start, P.ev[a]) != hipSuccess) return 0.f;
+        if (hipEventElapsedTime(&s1, T.start, P.ev[b]) != hipSuccess) return 0.f;
+        return std::max(0.f, std::min(s1, tail_len) - std::max(s0, 0.f));
+    }
 };
 
 static uint32_t choose_kp(uint64_t count, uint32_t k) {
@@ -462,6 +503,8 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
     P.trivial = true;
     P.mid_recorded = false;
     P.ev_used = 0; P.t0 = P.t1 = 0; P.scan_pairs.clear(); P.sample_pair = -1;
+    P.tail_pair = -1; P.early_sample = false; P.seq = idx->n_begun;
+    idx->tail_ev[P.seq & 3].armed = false;
     if (!nq) return VROD_OK;
     hipStream_t s = P.stream;
     Timer tm(idx, P);
@@ -728,6 +771,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             tm.arm(e0, e1);
             launch_scan_mfma(d, scan_dtype, idx->num_cus, s);
             P.sample_pair = (int)P.scan_pairs.size();
+            P.early_sample = early;
             P.scan_pairs.push_back({e0, e1});
             st.scan_launches++;
             // (the sample rows are scanned again by the first filtered stage: their time counts, their flops and
@@ -748,6 +792,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
                 ++pace_launch;
                 size_t e0, e1;
                 tm.arm(e0, e1);
+                if (li + 1 == bounds.size() && end == bounds[li]) tm.arm_tail();
                 launch_scan_mfma(a, scan_dtype, idx->num_cus, s);
                 P.scan_pairs.push_back({e0, e1});
                 st.scan_launches++;
@@ -1074,9 +1119,11 @@ static int search_complete(vrod_index* idx, Pending& P) {
         }
     }
     if (idx->profiling) {
-        for (auto& pr : P.scan_pairs) st.scan_ms += tm.ms(pr.first, pr.second);
-        if (P.sample_pair >= 0 && (size_t)P.sample_pair < P.scan_pairs.size())
-            st.sample_ms = tm.ms(P.scan_pairs[P.sample_pair].first, P.scan_pairs[P.sample_pair].second);
+        for (size_t i = 0; i < P.scan_pairs.size(); ++i) st.scan_ms += tm.pair_ms(i);
+        if (P.sample_pair >= 0 && (size_t)P.sample_pair < P.scan_pairs.size()) {
+            st.sample_ms = tm.pair_ms((size_t)P.sample_pair);
+            st.overlap_ms = tm.sample_overlap_ms();
+        }
         if (idx->profiling >= 2) st.total_ms = tm.ms(P.t0, P.t1);
     }
     idx->stats = st;
@@ -1427,7 +1474,7 @@ static int composite_end(vrod_index* idx, uint64_t* host_ids, float* host_scores
         idx->stats.fallback_queries += st.fallback_queries;
         idx->stats.band_queries += st.band_queries;
         idx->stats.split_pass |= st.split_pass;
-        if (st.scan_ms > idx->stats.scan_ms) idx->stats.sample_ms = st.sample_ms;   // of the shard whose scans took longest
+        if (st.scan_ms > idx->stats.scan_ms) { idx->stats.sample_ms = st.sample_ms; idx->stats.overlap_ms = st.overlap_ms; }   // of the shard whose scans took longest
         idx->stats.scan_ms = std::max(idx->stats.scan_ms, st.scan_ms);
         idx->stats.total_ms = std::max(idx->stats.total_ms, st.total_ms);
         idx->stats.scan_bytes += st.scan_bytes; idx->stats.scan_flops += st.scan_flops;
@@ -1607,6 +1654,7 @@ int vrod_index_destroy(vrod_index* idx) {
         for (DevBuf* b : {&P.band_idx, &P.band_q, &P.band_q_lp, &P.band_planes, &P.band_small, &P.band_ids, &P.band_scores}) b->release();
         if (P.gexec) (void)hipGraphExecDestroy(P.gexec);
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
+        for (auto& T : idx->tail_ev) { if (T.start) (void)hipEventDestroy(T.start); if (T.stop) (void)hipEventDestroy(T.stop); T = {}; }
         if (P.done) (void)hipEventDestroy(P.done);
         if (P.scans_done) (void)hipEventDestroy(P.scans_done);
         if (P.mid_done) (void)hipEventDestroy(P.mid_done);
@@ -1809,6 +1857,16 @@ int vrod_index_set_profiling(vrod_index* idx, int on) {
 int vrod_index_last_stats(const vrod_index* idx, vrod_search_stats* out) {
     if (!idx || !out) return fail(VROD_ERR_INVALID_ARG, "null argument");
     *out = idx->stats;
+    return VROD_OK;
+}
+
+int vrod_index_shard_stats(const vrod_index* idx, uint32_t shard, int* out_device, vrod_search_stats* out) {
+    if (!idx || !out) return fail(VROD_ERR_INVALID_ARG, "null argument");
+    const size_t n = idx->composite() ? idx->shards.size() : 1;
+    if (shard >= n) return fail(VROD_ERR_INVALID_ARG, "shard %u of a handle with %zu", shard, n);
+    const vrod_index* sh = idx->composite() ? idx->shards[shard] : idx;
+    *out = sh->stats;
+    if (out_device) *out_device = sh->device;
     return VROD_OK;
 }
 

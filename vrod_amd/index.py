@@ -106,6 +106,15 @@ class Index:
         check(self._L.vrod_index_last_stats(self._h, C.byref(st)))
         return st.as_dict()
 
+    def shard_stats(self, shard: int) -> dict:
+        """Counters of one shard of the last completed search + the device it lives on."""
+        st = SearchStats()
+        dev = C.c_int32(-1)
+        check(self._L.vrod_index_shard_stats(self._h, int(shard), C.byref(dev), C.byref(st)))
+        d = st.as_dict()
+        d["device"] = dev.value
+        return d
+
     # -- search
     def search(self, queries: np.ndarray, k: int):
         """numpy [nq, dim] fp32 -> (ids uint64 [nq, k], scores float32 [nq, k])."""
