@@ -373,6 +373,7 @@ def main_inprocess(args):
                      "frac": round(per_gpu / peak, 4), "traffic": None, "traffic_source": "not measured in this run",
                      "kernel": "scan_mfma_w4_kernel", "note": "per GPU: all devices' algorithmic flops / N / the slowest device's scan time per batch",
                      "launches_per_step": acc["launches"] / max(args.steps, 1)},
+        "library": va.version(),
         "exactness": {"certificate_fallback_queries": acc["fallback"]},
     }
     if len(devs) > 1:   # what each shard's device spent scanning, per batch (vrod_index_shard_stats)
@@ -563,6 +564,7 @@ def main():
                        "corpus_seed": CORPUS_SEED, "query_seed": QUERY_SEED,
                        "batches_in_flight": 1 if os.environ.get("VROD_BENCH_PIPELINE") == "0" else 2},
             "roofline": roofline,
+            "library": va.version(),   # names the hipcc that built the device code (the register audit ran on ITS output)
             "exactness": {"certificate_fallback_queries": fallback_total, "resolved_by_band_pass": acc["band"],
                           "max_fast_err": acc["max_err"], "eps_bound": acc["eps"],
                           "note": "ids and score bits equal the CPU oracle by construction (canonical re-score + certificate)"},

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def assert_multi_gpu_fields(out):
     """BASELINE.json's metric is QPS + recall@10 vs the CPU reference at 1/2/4/8 GPUs: the three fields of an N > 1 line"""
     assert out["verify_merged_equals_single_device"] is True
+    assert "hipcc" in out["library"]          # vrod_version(): the compiler that built the device code
     assert out["recall_at_10"] == 1.0
     assert out["bit_exact_vs_oracle_on_sample"] is True
     assert "oracle_sample" in out and "parity" in out

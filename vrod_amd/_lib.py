@@ -96,6 +96,11 @@ def load() -> C.CDLL:
     return L
 
 
+def version() -> str:
+    """vrod_version(): library version + the hipcc that built the device code."""
+    return load().vrod_version().decode()
+
+
 def check(rc: int) -> None:
     if rc != 0:
         raise VrodError(rc, load().vrod_last_error().decode("utf-8", "replace"))
