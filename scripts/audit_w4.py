@@ -8,7 +8,8 @@ compiler itself keeps out of the AGPRs wherever the accumulators are live: no v_
 no a[..] operand outside ;;#ASMSTART/;;#ASMEND from the first asm MFMA on (the accumulators are
 dead in the prologue of a query block: its first MFMAs are the C = 0 form, so compiler
 temporaries parked in AGPRs there are harmless -- hipcc does that for the L2 variant), no
-scratch anywhere (spills go to AGPRs first), accum_offset <= 256.
+scratch anywhere (spills go to AGPRs first), accum_offset <= 256; the compiler never names m0 (the
+asm LDS-DMA pieces own it) and emits no vmcnt wait of its own inside a block of the scan loop.
 
 scan_mfma_w4a_kernel also loads its A fragments with inline-asm global_load_dwordx4 (uncounted by
 hipcc): between such a load and the counted wait that names its registers the data is in flight, so
@@ -99,9 +100,20 @@ def audit(path):
         n_out = n_mfma = n_pro = 0
         last_touch = first_mfma = -1
         labels, branches = {}, []
-        for ln, line in enumerate(body.split("\n")):
+        blk_mfma, blk_waits = 0, []   # the basic block being read: its asm MFMAs, its compiler-emitted vmcnt waits
+        for ln, line in enumerate(body.split("\n") + [".LBB_end:"]):
             lab = re.match(r"^(\.LBB\w+):", line)
             if lab:
+                # The scan loop keeps 16-32 LDS-DMA pieces in flight that hipcc's counter bookkeeping cannot see (asm); its own
+                # waits are asm too.  A vmcnt wait the COMPILER puts into a block of the loop (it does when compiler-visible
+                # loads / stores are left pending at the loop's back edge) drains that queue every K-tile: +16 %, same results.
+                # (Not asked of the every-score sample form, <METRIC, 1, SPLIT>: one tile per work-group, 64 K compiler-visible
+                #  score stores behind it -- there is no queue to keep.)
+                if blk_mfma >= 32 and not re.search(r"kernelILi\dELi1ELb", name):
+                    for w in blk_waits:
+                        n_out += 1
+                        print(f"{name}: compiler-emitted vmcnt wait inside a block of {blk_mfma} MFMAs: {w}")
+                blk_mfma, blk_waits = 0, []
                 labels[lab.group(1)] = ln
             br = re.search(r"\bs_c?branch\w*\s+(\.LBB\w+)", line.split(";")[0])
             if br:
@@ -116,9 +128,12 @@ def audit(path):
             if inasm:
                 if "v_mfma" in code:
                     n_mfma += 1
+                    blk_mfma += 1
                     if first_mfma < 0:
                         first_mfma = ln
                 continue
+            if re.search(r"\bs_waitcnt\b.*\bvmcnt\(", code):
+                blk_waits.append(line.strip())
             if re.search(r"\bm0\b", code):   # M0 is set by the asm LDS-DMA pieces only: the compiler must have no use of its own for it
                 n_out += 1
                 print(f"{name}: compiler names m0: {line.strip()}")
