@@ -186,6 +186,11 @@ struct vrod_index {
     // sample launch may overlap it, and measures by how much when it completes
     struct TailEv { hipEvent_t start = nullptr, stop = nullptr; bool armed = false; };
     TailEv tail_ev[4];
+    // Self-tuning candidate margin of the batched scan (search_enqueue_body / search_complete): k' = k + margin * kp_boost.
+    // A failed certificate costs a band pass (one more scan of the corpus); doubling the margin costs a few per cent
+    // of hits.  kp_boost doubles (up to 4) after a search with failures, halves after 64 clean ones; failures AT 4 mean
+    // the margin is not what those queries lack (exact duplicates): back to 1 and left alone for 256 searches.
+    uint32_t kp_boost = 1, kp_clean = 0, kp_hold = 0;
     uint32_t n_begun = 0, n_ended = 0;   // searches enqueued / completed: slot = counter & 1
     hipEvent_t caller_ev = nullptr;      // orders the caller's stream before ours
 
@@ -562,7 +567,9 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         // 1.75 / 1.80 ms); a failed certificate costs a band pass, not a wrong result.  (The L2 bound through the
         // norm expansion is ~4x wider relative to the gaps: it keeps 16.)
         static const uint32_t margin_env = [] { const char* e = getenv("VROD_DEBUG_KP_MARGIN"); return e ? (uint32_t)atoi(e) : 0u; }();
-        kp = (uint32_t)std::min<uint64_t>(N, (uint64_t)k + std::max<uint32_t>(margin_env ? margin_env : 8, k / 8));
+        kp = (uint32_t)std::min<uint64_t>(N, (uint64_t)k + (uint64_t)std::max<uint32_t>(margin_env ? margin_env : 8, k / 8) * idx->kp_boost);
+    } else if (path == VROD_PATH_MFMA) {
+        kp = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(N, kSelectChunk / 2), (uint64_t)k + (uint64_t)std::max<uint32_t>(16, k / 8) * idx->kp_boost);
     }
     st.kprime = kp;
     P.N = N; P.kp = kp;
@@ -1116,6 +1123,17 @@ static int search_complete(vrod_index* idx, Pending& P) {
             float band_err = 0.f;
             HIP_TRY(hipMemcpy(&band_err, &P.flags[4], 4, hipMemcpyDeviceToHost));
             st.max_fast_err = std::max(st.max_fast_err, band_err);
+        }
+    }
+    if (P.path == VROD_PATH_MFMA && !P.split && P.nq) {   // the margin follows what the certificates say (vrod_index::kp_boost)
+        if (idx->kp_hold) --idx->kp_hold;
+        if (st.fallback_queries) {
+            idx->kp_clean = 0;
+            if (idx->kp_boost >= 4) { idx->kp_boost = 1; idx->kp_hold = 256; }
+            else if (!idx->kp_hold) idx->kp_boost *= 2;
+        } else if (++idx->kp_clean >= 64 && idx->kp_boost > 1) {
+            idx->kp_boost /= 2;
+            idx->kp_clean = 0;
         }
     }
     if (idx->profiling) {
