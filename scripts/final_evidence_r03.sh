@@ -4,6 +4,7 @@
 set -o pipefail
 O=gpurun_out/final; mkdir -p $O
 B="--no-cpu-baseline --no-hbm-probe --no-host-probe"
+python -c "import __graft_entry__ as g; g.smoke()" > $O/k_smoke.log 2>&1 &&
 python bench.py --steps 20 --warmup 5 > $O/k_bench_default.json 2> $O/k_bench_default.err &&
 python bench.py --steps 400 --warmup 5 $B > $O/k_sustained_400_batches.json 2> $O/s.err &&
 VROD_BENCH_FORCE_COLLECTIVE=1 VROD_BENCH_VERIFY=0 python bench.py --rows 1250000 --steps 200 --warmup 10 $B > $O/k_shard_1p25M_with_exchange.json 2> $O/sh.err &&
@@ -18,7 +19,10 @@ rocprofv3 --kernel-trace --output-format csv -d $O/t10 -- python3 scripts/ab_pro
 python scripts/step_timeline.py $O/t10 > $O/k_step_timeline_10M.txt &&
 rocprofv3 --kernel-trace --output-format csv -d $O/t1 -- python3 scripts/ab_probe.py 1250000 1024 6 > $O/t1.log 2>&1 &&
 python scripts/step_timeline.py $O/t1 > $O/k_step_timeline_1p25M_shard.txt &&
-rm -rf $O/t10 $O/t1 &&
+rocprofv3 --kernel-trace --output-format csv -d $O/tp -- python3 bench.py --steps 12 --warmup 3 --rows 1250000 $B > $O/tp.json 2> $O/tp.err &&
+python scripts/pipeline_timeline.py $O/tp 2 > $O/s_pipeline_timeline_shard.txt &&
+python scripts/probes/k_probe.py 8000000 1024 768 bf16 "10 100 1000" 2>&1 | grep -v amdgpu.ids > $O/k_probe_k_8Mx768_q1024.txt &&
+rm -rf $O/t10 $O/t1 $O/tp &&
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/final/k_*.json')):
