@@ -74,7 +74,8 @@ enum { VROD_PATH_AUTO = 0, VROD_PATH_STREAM = 1, VROD_PATH_MFMA = 2, VROD_PATH_E
 /* Counters of the most recently COMPLETED search on a handle (bench.py / tests read these). */
 typedef struct {
     uint32_t path;              /* VROD_PATH_* actually taken */
-    uint32_t nq, k, kprime;     /* kprime = candidates re-scored per query */
+    uint32_t nq, k, kprime;     /* kprime = candidates re-scored per query (k + a margin that follows the certificates:
+                                 * doubled after a search in which some failed, halved after 64 clean searches) */
     uint32_t scan_launches;     /* launches of the dominant scan kernel */
     uint32_t fallback_queries;  /* queries whose certificate failed -> exact path */
     float scan_ms;              /* HIP-event time of the scan kernel launches (sum, sample pass included) */

@@ -153,6 +153,17 @@ def test_synthetic_add_small_corpus_and_device_pointers(va, oracle):
     assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))
 
 
+def test_shard_stats_of_a_single_device_handle_are_its_own(va, oracle):
+    raw = oracle.synth_rows(3, 0, 5000, 64)
+    with va.Index(64, "f32", "l2") as ix:
+        ix.add(raw)
+        ix.search(oracle.synth_rows(2, 0, 3, 64), 5)
+        st, sh = ix.last_stats(), ix.shard_stats(0)
+        assert sh.pop("device") == 0 and sh == st
+        with pytest.raises(va.VrodError):
+            ix.shard_stats(1)
+
+
 def test_rejected_add_rolls_every_shard_back(va, oracle):
     dim = 16
     raw = oracle.synth_rows(1, 0, 140000, dim, threads=8)

@@ -413,9 +413,48 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const float* __restr
     if (tid == 0) thr[blockIdx.x] = key_to_score_rt(prefix, METRIC);
 }
 
+// The grouped sample pass leaves at most a few hundred group bests per query (512 at batch 1024): one WAVE per query, the
+// keys in registers (up to 16 per lane), the j-th largest built bit by bit from the top -- 32 rounds of compare + ballot +
+// popcount, no LDS, no barrier, one dependent load.  Same value as the block kernel above (the exact j-th largest key;
+// nothing written when fewer than j keys are valid), 7 us instead of 20 in front of every batch's first filtered stage.
+constexpr uint32_t kSampleWaveMax = 1024;
+template <int METRIC>
+__global__ __launch_bounds__(256) void sample_select_wave_kernel(const float* __restrict__ scores, uint64_t score_ld, uint32_t n,
+                                                                 uint32_t j, uint32_t nq, float* __restrict__ thr) {
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (q >= nq) return;
+    const float* sc = scores + (uint64_t)q * score_ld;
+    uint32_t key[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const uint32_t i = (uint32_t)u * 64u + lane;
+        key[u] = i < n ? score_key<METRIC>(sc[i]) : 0u;   // NaN padding and the slots past n: key 0, never counted
+    }
+    uint32_t valid = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) valid += (uint32_t)__builtin_popcountll(__ballot(key[u] != 0u));
+    if (valid < j) return;
+    uint32_t prefix = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = prefix | (1u << bit);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) cnt += (uint32_t)__builtin_popcountll(__ballot(key[u] >= cand));
+        if (cnt >= j) prefix = cand;     // at least j keys are >= cand: the j-th largest has this bit set
+    }
+    if (lane == 0) thr[q] = key_to_score_rt(prefix, METRIC);
+}
+
 void launch_sample_select(const float* d_scores, uint64_t score_ld, uint32_t n_sample, int nq,
                           int metric, uint32_t j, float* d_thr, hipStream_t s) {
     if (!nq) return;
+    if (n_sample <= kSampleWaveMax && j >= 1) {
+        const int grid = (nq + 3) / 4;
+        if (metric == M_COSINE) sample_select_wave_kernel<M_COSINE><<<grid, 256, 0, s>>>(d_scores, score_ld, n_sample, j, (uint32_t)nq, d_thr);
+        else sample_select_wave_kernel<M_L2><<<grid, 256, 0, s>>>(d_scores, score_ld, n_sample, j, (uint32_t)nq, d_thr);
+        return;
+    }
     if (metric == M_COSINE) sample_select_kernel<M_COSINE><<<nq, 256, 0, s>>>(d_scores, score_ld, n_sample, j, d_thr);
     else sample_select_kernel<M_L2><<<nq, 256, 0, s>>>(d_scores, score_ld, n_sample, j, d_thr);
 }
