@@ -202,9 +202,9 @@ def cpu_baseline(wl, va, torch, dev, n_total):
     # reported against the fp32-data oracle, labelled separately"), on a smaller query sample
     corpus32 = O.prepare(raw, DT["f32"], ME[wl["metric"]], threads=cores) if wl["dtype"] == "bf16" else None
     del raw
-    # size the query samples for ~12 s (all cores) and ~6 s (one thread) at ~2.5e9 mul-add/s/thread
+    # size the query samples for ~12 s (all cores) and ~10 s (one thread) at ~2.5e9 mul-add/s/thread
     q_all = int(max(2, min(512, 12.0 * 2.5e9 * cores / (ns * dim))))
-    q_one = int(max(1, min(16, 6.0 * 2.5e9 / (ns * dim))))
+    q_one = int(max(1, min(32, 10.0 * 2.5e9 / (ns * dim))))
     rq = O.synth_rows(QUERY_SEED, 0, q_all, dim)
     pq = O.prepare(rq, DT[wl["dtype"]], ME[wl["metric"]])
     gen_s = time.time() - t
