@@ -45,3 +45,28 @@ def test_margin_follows_the_certificates(va, oracle):
     assert seen[0][1] == seen[0][2], seen                           # ... and the band pass resolved every failure
     assert kps[1] == k + 24 and kps[2] >= kps[1], seen              # the margin doubled
     assert seen[3][1] == 0, seen                                    # and no certificate fails any more
+
+
+def test_widest_k_after_the_margin_was_raised(va, oracle):
+    """k = VROD_MAX_K on a handle whose margin multiplier is at its largest: k' must stay inside the select windows
+    (k' <= 4096), and the result exact.  The corpus is 50 copies of 1000 rows: more copies than any margin of a k = 10
+    search holds (18, 26, 42), so every certificate fails (ties across the k-th boundary) and the band pass answers."""
+    dim, base_n, copies = 64, 1000, 50
+    base = oracle.synth_rows(5, 0, base_n, dim)
+    raw = np.tile(base, (copies, 1))
+    with va.Index(dim, "bf16", "cosine") as ix:
+        ix.add(raw)
+        ix.set_path(va.PATH_MFMA)
+        kps = []
+        for s in range(2):                              # two searches whose certificates all fail: x2, x4
+            ids, sc = ix.search(base[s * 16:(s + 1) * 16], 10)
+            st = ix.last_stats()
+            kps.append(st["kprime"])
+            assert st["fallback_queries"] == 16
+        rq = oracle.synth_rows(2, 0, 6, dim)
+        k = va.MAX_K
+        ids, sc = ix.search(rq, k)
+        st = ix.last_stats()
+        assert kps == [18, 26] and st["kprime"] == 4096, (kps, st)
+        oi, osc = oracle.search(raw, rq, k, 1, 0, threads=8)
+        assert np.array_equal(ids, oi) and np.array_equal(bits(sc), bits(osc))

@@ -567,7 +567,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         // 1.75 / 1.80 ms); a failed certificate costs a band pass, not a wrong result.  (The L2 bound through the
         // norm expansion is ~4x wider relative to the gaps: it keeps 16.)
         static const uint32_t margin_env = [] { const char* e = getenv("VROD_DEBUG_KP_MARGIN"); return e ? (uint32_t)atoi(e) : 0u; }();
-        kp = (uint32_t)std::min<uint64_t>(N, (uint64_t)k + (uint64_t)std::max<uint32_t>(margin_env ? margin_env : 8, k / 8) * idx->kp_boost);
+        kp = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(N, kSelectChunk / 2), (uint64_t)k + (uint64_t)std::max<uint32_t>(margin_env ? margin_env : 8, k / 8) * idx->kp_boost);
     } else if (path == VROD_PATH_MFMA) {
         kp = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(N, kSelectChunk / 2), (uint64_t)k + (uint64_t)std::max<uint32_t>(16, k / 8) * idx->kp_boost);
     }
