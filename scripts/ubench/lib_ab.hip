@@ -94,7 +94,6 @@ int main(int argc, char** argv) {
         if (xcd[v] && xcd[v](xk, 1) == 0)
             for (int x = 0; x < 8; ++x) if (xk[x * 4 + 3]) printf("    XCC %d: %llu work-groups, loop avg %.1f us, min %.1f, max %.1f\n", x, xk[x * 4 + 3],
                 (double)xk[x * 4] / (double)xk[x * 4 + 3] * 0.01, (double)(~xk[x * 4 + 2]) * 0.01, (double)xk[x * 4 + 1] * 0.01);
-        if (clk[v] && ck[1]) printf("    per work-group scan loop: min %.1f us, max %.1f us (last launch: first start -> last end %.1f us)\n", (double)(~ck[8]) * 0.01, (double)ck[7] * 0.01, (double)(ck[9] - ~ck[10]) * 0.01);
     }
     return 0;
 }
