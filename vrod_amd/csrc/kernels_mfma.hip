@@ -69,7 +69,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
     }
     if (dtype == DT_BF16) {
         // sibling pacing interval of the 4-wave kernel, in K-tiles (0 = off; VROD_DEBUG_PACE_KT for A/B runs)
-        static const int pace_kt = [] { const char* e = getenv("VROD_DEBUG_PACE_KT"); return e ? atoi(e) : 192; }();
+        const int pace_kt = debug_env().pace_kt;
         const uint32_t nqb_total = a.nqb;
         for (uint32_t qb_base = 0; qb_base < nqb_total; qb_base += a.slots) {   // one launch unless nq > 256 * slots
             a.qb_base = qb_base;
@@ -81,7 +81,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
             if (a.pace_every && (qb_base > 0 || !h.pace_is_zero)) (void)hipMemsetAsync(a.pace, 0, a.nstrips * sizeof(uint32_t), s);
             const int form = !h.dense_out ? 0 : a.dense_group ? 2 : 1;
             // work stealing (kernels_mfma_w4.hip): the claim bits of this launch start at zero.  VROD_DEBUG_W4_STEAL=0: static shares (A/B runs)
-            static const bool steal_on = [] { const char* e = getenv("VROD_DEBUG_W4_STEAL"); return !e || e[0] != '0'; }();
+            const bool steal_on = debug_env().w4_steal;
             a.claims = (form == 0 && steal_on && h.claims && (size_t)a.nqb * a.nstrips <= kMfmaClaimWords) ? h.claims : nullptr;
             if (a.claims && (qb_base > 0 || !h.claims_is_zero)) (void)hipMemsetAsync(a.claims, 0, (size_t)a.nqb * a.nstrips * sizeof(uint32_t), s);
             launch_mfma_w4(a, h.metric, form, split, grid, s, first_launch ? lev.start : nullptr, last_launch ? lev.stop : nullptr);
@@ -89,7 +89,7 @@ void launch_scan_mfma(const MfmaScanArgs& h, int dtype, int num_cus, hipStream_t
         return;
     }
     // fp32 rows: the 8-wave phased kernel; pacing in tiles, only where several work-groups share a strip
-    static const int pace_tiles = [] { const char* e = getenv("VROD_DEBUG_PACE"); return e ? atoi(e) : 16; }();
+    const int pace_tiles = debug_env().pace_tiles;
     a.strips_per_xcd = a.nqb <= a.slots ? a.slots / a.nqb : 1;
     a.nstrips = 8 * a.strips_per_xcd;
     a.pace_every = (h.pace && a.nqb > 1 && a.nqb <= a.slots && pace_tiles > 0) ? (uint32_t)pace_tiles : 0u;

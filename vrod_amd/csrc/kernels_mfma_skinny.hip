@@ -280,8 +280,7 @@ __global__ __launch_bounds__(kSkWaves * 64) void scan_mfma_skinny_kernel(const M
 // Largest batch the skinny kernel takes for rows of `row_bytes` (bf16 rows, or the [hi | lo] planes
 // of the split pass): what fits in LDS beside the wave logs.  0: none (VROD_DEBUG_SKINNY=0, long rows).
 uint32_t mfma_skinny_max_queries(bool split, uint32_t row_bytes) {
-    static const bool skinny_on = [] { const char* e = getenv("VROD_DEBUG_SKINNY"); return !e || e[0] != '0'; }();
-    if (!skinny_on) return 0;
+    if (!debug_env().skinny) return 0;
     const uint32_t lds_cap = 160u * 1024u;
     if (!split) return skinny_lds_bytes<4>(row_bytes) <= lds_cap ? 64u : skinny_lds_bytes<2>(row_bytes) <= lds_cap ? 32u : 0u;
     return skinny_lds_bytes<2>(row_bytes) <= lds_cap ? 32u : skinny_lds_bytes<1>(row_bytes) <= lds_cap ? 16u : 0u;

@@ -341,6 +341,30 @@ static int index_add(vrod_index* idx, const float* rows, uint64_t n, bool synthe
     return VROD_OK;
 }
 
+// ------------------------------------------------------------------ experiment switches
+namespace vrod {
+const DebugEnv& debug_env() {
+    static const DebugEnv env = [] {
+        DebugEnv d;
+        auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e && *e ? atoll(e) : dflt; };
+        auto on = [](const char* name) { const char* e = getenv(name); return !e || e[0] != '0'; };
+        d.pace_kt = (int)num("VROD_DEBUG_PACE_KT", d.pace_kt);
+        d.pace_tiles = (int)num("VROD_DEBUG_PACE", d.pace_tiles);
+        d.w4_steal = on("VROD_DEBUG_W4_STEAL");
+        d.skinny = on("VROD_DEBUG_SKINNY");
+        d.stage_growth = (uint64_t)num("VROD_DEBUG_STAGE_GROWTH", 0);
+        d.sample_rows = (uint64_t)num("VROD_DEBUG_SAMPLE_ROWS", 0);
+        d.kp_margin = (uint32_t)num("VROD_DEBUG_KP_MARGIN", 0);
+        if (const char* e = getenv("VROD_DEBUG_EARLY_SAMPLE")) d.early_sample = e[0] != '0' ? 1 : 0;
+        d.sample_grouped = on("VROD_DEBUG_SAMPLE_GROUPED");
+        d.graph = on("VROD_DEBUG_GRAPH");
+        d.band = on("VROD_DEBUG_BAND");
+        return d;
+    }();
+    return env;
+}
+}  // namespace vrod
+
 // ------------------------------------------------------------------ search pipeline
 struct Timer {
     vrod_index* idx;
@@ -468,12 +492,12 @@ static StagePlan plan_stages(uint64_t N, uint32_t kp, uint32_t cap, uint32_t max
     // three waves of the work-group waiting at the next barrier for the wave that walks a hit column (~0.35 us of
     // work-group time per append, not 0.1), against ~40 us of ramp + compaction per extra stage: g = 5 at every size.
     // VROD_DEBUG_STAGE_GROWTH overrides (tuning).
-    static const uint64_t g_env = [] { const char* e = getenv("VROD_DEBUG_STAGE_GROWTH"); return e ? (uint64_t)atoi(e) : 0ull; }();
+    const uint64_t g_env = debug_env().stage_growth;
     const uint64_t g_auto = 5;
     const uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(g_env ? g_env : g_auto, cap / (3ull * kp)));
     // sample: N/g^2 rows, at most one round of work-groups (one 256-row tile per work-group of
     // the dense launch)
-    static const uint64_t s_env = [] { const char* e = getenv("VROD_DEBUG_SAMPLE_ROWS"); return e ? (uint64_t)atoll(e) : 0ull; }();   // tuning knob
+    const uint64_t s_env = debug_env().sample_rows;   // tuning knob
     if (s_env) max_sample_rows = (uint32_t)std::min<uint64_t>(s_env, max_sample_rows);
     uint64_t S = std::min<uint64_t>(N / (g * g), max_sample_rows);
     S = std::max<uint64_t>(S, std::min<uint64_t>(N, std::max<uint64_t>(4ull * kp, kRowTile)));
@@ -566,7 +590,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         // 30 720 queries and 12.58-12.65 / 12.53 / 12.51 / 13.27 / 15.44 ms per batch (1.25M-row shard: 1.82 / - /
         // 1.75 / 1.80 ms); a failed certificate costs a band pass, not a wrong result.  (The L2 bound through the
         // norm expansion is ~4x wider relative to the gaps: it keeps 16.)
-        static const uint32_t margin_env = [] { const char* e = getenv("VROD_DEBUG_KP_MARGIN"); return e ? (uint32_t)atoi(e) : 0u; }();
+        const uint32_t margin_env = debug_env().kp_margin;
         kp = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(N, kSelectChunk / 2), (uint64_t)k + (uint64_t)std::max<uint32_t>(margin_env ? margin_env : 8, k / 8) * idx->kp_boost);
     } else if (path == VROD_PATH_MFMA) {
         kp = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(N, kSelectChunk / 2), (uint64_t)k + (uint64_t)std::max<uint32_t>(16, k / 8) * idx->kp_boost);
@@ -727,7 +751,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         // 5M 6.76 / 6.83, 10M 13.28-13.32 / 13.40-13.41 (-1.4 / -1.5 / -1.0 / -0.7 %).  Early is taken up to 6M rows per
         // handle: beyond, the gain is under 1 % and the sample pass squeezed beside a 7-ms stage makes that stage's own
         // launch time (what bench.py's roofline divides by) unreadable.  VROD_DEBUG_EARLY_SAMPLE=0 / 1 forces late / early.
-        static const int early_env = [] { const char* e = getenv("VROD_DEBUG_EARLY_SAMPLE"); return e ? (e[0] != '0' ? 1 : 0) : -1; }();
+        const int early_env = debug_env().early_sample;
         const bool early = early_env >= 0 ? early_env == 1 : N <= 6000000ull;
         Pending& O = idx->slot[&P == &idx->slot[0] ? 1 : 0];
         HIP_TRY(hipStreamWaitEvent(s, early ? O.mid_done : O.scans_done, 0));
@@ -765,7 +789,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
             // Grouped form where the kernel has it: the threshold is the j-th best of the per-group bests (groups of 32
             // rows: valid -- at least j rows are that good -- and exact unless two of the j best share a group), 1/32 of
             // the dense block to write and to select from.  Only while the groups outnumber j by 8x (else: every score).
-            static const bool group_env = [] { const char* e = getenv("VROD_DEBUG_SAMPLE_GROUPED"); return !e || e[0] != '0'; }();
+            const bool group_env = debug_env().sample_grouped;
             const uint32_t grows = group_env ? mfma_dense_group_rows(d, scan_dtype) : 0u;
             const uint32_t n_groups = grows ? (uint32_t)(round_up(sp.S, kRowTile) / grows) : 0u;
             const bool grouped = grows && (uint64_t)sp.j * 8 <= n_groups && sp.S % kRowTile == 0;   // whole tiles of real rows
@@ -844,7 +868,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
 // plain launches.
 static int search_enqueue(vrod_index* idx, Pending& P, const float* d_queries_raw, uint32_t nq, uint32_t k,
                           uint64_t* d_out_ids, float* d_out_scores) {
-    static const bool graphs_on = [] { const char* e = getenv("VROD_DEBUG_GRAPH"); return !e || e[0] != '0'; }();
+    const bool graphs_on = debug_env().graph;
     const uint64_t N = idx->count;
     int path = idx->path;
     if (path == VROD_PATH_AUTO && nq <= 4) path = VROD_PATH_STREAM;
@@ -933,7 +957,7 @@ static const uint32_t kBandMinQueriesFast = 2, kBandMinQueriesF32 = 48;
 static const uint32_t kBandKeep = kSelectChunk / 2;
 
 static int band_pass(vrod_index* idx, Pending& P, std::vector<uint32_t>& failed, uint32_t max_qn2_bits) {
-    static const bool band_on = [] { const char* e = getenv("VROD_DEBUG_BAND"); return !e || e[0] != '0'; }();
+    const bool band_on = debug_env().band;
     const uint32_t nf = (uint32_t)failed.size(), k = P.k;
     const uint64_t N = P.N;
     const uint32_t min_q = (idx->dtype == VROD_DTYPE_BF16 || P.split) ? kBandMinQueriesFast : kBandMinQueriesF32;

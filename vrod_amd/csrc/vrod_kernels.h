@@ -190,6 +190,24 @@ struct MfmaScanArgs {
     bool claims_is_zero;    // the caller already cleared them (else the launcher issues a memset)
 };
 void launch_scan_mfma(const MfmaScanArgs& a, int dtype, int num_cus, hipStream_t s);
+
+// Experiment switches (VROD_DEBUG_*): parsed ONCE per process, here and nowhere else (debug_env() in vrod_index.hip).
+// The defaults are what every measurement in DESIGN.md was taken with; they exist for A/B runs (scripts/env_sweep.sh),
+// not as a product surface -- the three variables a user may set are documented in include/vrod.h.
+struct DebugEnv {
+    int pace_kt = 192;            // VROD_DEBUG_PACE_KT: sibling pacing interval of the 4-wave scan, K-tiles (0: off)
+    int pace_tiles = 16;          // VROD_DEBUG_PACE: ... of the 8-wave fp32 scan, tiles (0: off)
+    bool w4_steal = true;         // VROD_DEBUG_W4_STEAL=0: static shares, no work stealing
+    bool skinny = true;           // VROD_DEBUG_SKINNY=0: batches of 5-64 queries take the 256-query tile
+    uint64_t stage_growth = 0;    // VROD_DEBUG_STAGE_GROWTH: rows grow x g per filtered stage (0: the default, 5)
+    uint64_t sample_rows = 0;     // VROD_DEBUG_SAMPLE_ROWS: cap on the sample pass's rows (0: none)
+    uint32_t kp_margin = 0;       // VROD_DEBUG_KP_MARGIN: starting candidate margin k' - k of the batched cosine scan (0: 8)
+    int early_sample = -1;        // VROD_DEBUG_EARLY_SAMPLE=0 / 1: order of the two searches in flight (-1: by corpus size)
+    bool sample_grouped = true;   // VROD_DEBUG_SAMPLE_GROUPED=0: the sample pass writes every score
+    bool graph = true;            // VROD_DEBUG_GRAPH=0: no hipGraph replay of small searches
+    bool band = true;             // VROD_DEBUG_BAND=0: failed certificates go straight to the exact path
+};
+const DebugEnv& debug_env();
 size_t mfma_dump_bytes(int num_cus);
 constexpr size_t kMfmaClaimWords = 256;    // >= query blocks per launch x strips (8 x work-groups per XCD in all)
 // Rows per group of the grouped sample form for this launch (32), or 0 when the kernel that would take it only
