@@ -545,9 +545,9 @@ def main():
         if wl["bound"] == "mfma":
             roofline["by_kernel"] = by_kernel
             if kernel == "scan_mfma_w4_kernel":   # context, NOT a value of this run
-                roofline["context"] = ("peak = 2.5 PF nominal (2.4 GHz); under MFMA load the chip holds ~1.85-2.1 GHz (power): the scan loop's "
-                                       "instruction mix alone measures 0.885 of peak with MFMAs only and 0.65 with the 256x256 tile's LDS-DMA "
-                                       "traffic (scripts/ubench/loop_mix.hip, profiles/r03/x_loop_mix.log)")
+                roofline["context"] = ("peak = 2.5 PF nominal (2.4 GHz); under MFMA load with real data the chip holds 1.85-2.2 GHz (power): the scan "
+                                       "loop's instruction mix alone measures 0.91 of peak with MFMAs only, 0.76 with the 256x256 tile's LDS fills "
+                                       "from L2 and ~0.68 at a search's HBM share (scripts/ubench/loop_mix.hip, profiles/r03/x_loop_mix.log)")
         if wl["bound"] == "mfma" and acc["overlap_ms"] > 0:
             # (vrod_index.hip: up to 6M rows per handle the next batch's sample pass runs beside this batch's last stage)
             roofline["overlap"] = {

@@ -5,6 +5,8 @@
 //   V2  + 4 LDS-DMA pieces per phase (s_add_u32 m0 one group ahead of its global_load_lds_dwordx4), counted vmcnt(16) +
 //         s_barrier every second phase
 //   V3  V2 without the barrier            V4  V2 with the pieces' source in a 64-KB region per work-group (all L2 hits)
+//   V6  V2 (rows streamed from HBM) with contiguous pieces: the corpus stored tile-major in LDS-image order
+//   V5  V4 with every piece 1 KB of CONTIGUOUS memory (an operand stored in LDS-image order) instead of 8 rows x 128 B
 // prints shader cycles per MFMA and the in-kernel clock.
 //   hipcc --offload-arch=gfx950 -O3 -o loop_mix loop_mix.hip && ./loop_mix
 #include <hip/hip_runtime.h>
@@ -19,15 +21,30 @@
 #define RD(R, O) "ds_read_b128 v[" #R ":" #R "+3], %0 offset:" #O "\n\t"
 #define M0(I) "s_add_u32 m0, %1, " #I "\n\t"
 #define DMA(V) "global_load_lds_dwordx4 %" #V ", %6\n\t"
+__global__ void fill(uint32_t* p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (h & 0x807F807Fu) | 0x3D803D80u;
+    }
+}
 template <int V>
 __global__ __launch_bounds__(256) void k(unsigned long long* out, const char* src, int iters, size_t wg_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     asm volatile("" ::: "a0", "a63", VCLOB);
+    {   // MFMA operands with real bit patterns (all-zero operands toggle nothing: the chip then holds 2.39 GHz and the
+        // numbers mean nothing): bf16 pairs of random sign and mantissa around 2^-4, different per lane and register
+        uint32_t h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#define FILL(R) h = h * 1664525u + 1013904223u; asm volatile("v_mov_b32 v" #R ", %0" :: "v"((h & 0x807F807Fu) | 0x3D803D80u) : "v" #R);
+        FILL(64) FILL(65) FILL(66) FILL(67) FILL(68) FILL(69) FILL(70) FILL(71) FILL(72) FILL(73) FILL(74) FILL(75) FILL(76) FILL(77) FILL(78) FILL(79)
+        FILL(80) FILL(81) FILL(82) FILL(83) FILL(84) FILL(85) FILL(86) FILL(87) FILL(88) FILL(89) FILL(90) FILL(91) FILL(92) FILL(93) FILL(94) FILL(95)
+#undef FILL
+    }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t lds_rd = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + lane * 16u + wave * 8192u;
     const uint32_t lds_w = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + 65536u + wave * 16384u);
-    const uint32_t v0 = (lane >> 3) * 1536u + ((lane & 7) << 4), v1 = v0 + 8 * 1536u, v2 = v0 + 16 * 1536u, v3 = v0 + 24 * 1536u;
-    const char* base = src + (size_t)blockIdx.x * wg_stride + wave * 65536u;
+    const uint32_t v0 = (V == 5 || V == 6) ? lane * 16u : (lane >> 3) * 1536u + ((lane & 7) << 4);
+    const uint32_t v1 = v0 + ((V == 5 || V == 6) ? 1024u : 8 * 1536u), v2 = v0 + ((V == 5 || V == 6) ? 2048u : 16 * 1536u), v3 = v0 + ((V == 5 || V == 6) ? 3072u : 24 * 1536u);
+    const char* base = src + (size_t)blockIdx.x * wg_stride + wave * (V == 6 ? 4096u : 65536u);
     const uint64_t bv = (uint64_t)base;
     auto uni = [](uint64_t v) {   // (the builtin returns int: cast before widening)
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -49,9 +66,11 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, const char* sr
             asm volatile("s_waitcnt lgkmcnt(0)\n\t" M0(4096) G0 RD(96, 0) RD(100, 1024) DMA(2) G1 RD(104, 2048) RD(108, 3072) M0(5120) G2 RD(112, 4096) RD(116, 5120) DMA(3) G3 RD(120, 6144) RD(124, 7168) M0(6144)
                          G0 DMA(4) G1 M0(7168) G2 DMA(5) G3
                          :: "v"(lds_rd), "s"(lds_w), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sb) : "memory", "scc", VCLOB);
-            if constexpr (V == 2 || V == 4) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            if constexpr (V == 2 || V == 4 || V == 5 || V == 6) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            if constexpr (V != 4) { sb += 128; if ((i & 7) == 7) sb += 256 * 1536 - 8 * 128; }   // walk a row-major corpus K-tile by K-tile
+            if constexpr (V == 6) sb += 16384;   // the work-group's four waves read 4 x 4 KB of fresh, contiguous memory per iteration (64 MB per work-group)
+            else if constexpr (V != 4 && V != 5) { sb += 128; if ((i & 7) == 7) sb += 256 * 1536 - 8 * 128; }   // walk a row-major corpus K-tile by K-tile
+            if ((i % 4000) == 3999) sb = base;   // (the walk wraps: every variant runs long enough for the clock to settle)
             sb = uni((uint64_t)sb);
         }
     }
@@ -61,17 +80,18 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, const char* sr
 }
 int main() {
     unsigned long long* d; (void)hipMalloc(&d, 256); (void)hipMemset(d, 0, 256);
-    const int iters = 4000;   // x 64 MFMAs
-    const size_t wg_stride = (size_t)(iters / 8 + 2) * 256 * 1536 + (1 << 20);   // every work-group walks its own rows (HBM), V4: stays in 256 KB
+    const int iters = 60000;   // x 64 MFMAs: ~35 ms per launch; the walk of the HBM variants wraps every 4000
+    const size_t wg_stride = (size_t)(4000 / 8 + 2) * 256 * 1536 + (1 << 20);   // every work-group walks its own rows (HBM), V4: stays in 256 KB
     char* src; if (hipMalloc(&src, wg_stride * 256) != hipSuccess) { printf("alloc failed\n"); return 1; }
-    (void)hipMemset(src, 0, wg_stride * 256);
+    fill<<<4096, 256>>>((uint32_t*)src, wg_stride * 256 / 4);   // random bytes: what moves through L2 -> LDS toggles like data
     const int lds_bytes = 65536 + 4 * 16384;
 #define RUN(V) (void)hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); k<V><<<256, 256, lds_bytes>>>(d, src, iters, wg_stride);
-    for (int r = 0; r < 2; ++r) { RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) }
+    // each variant three times in a row (the clock settles over tens of ms), the last one counts; two rounds, the second reported
+    for (int r = 0; r < 2; ++r) { RUN(0) RUN(0) RUN(0) RUN(1) RUN(1) RUN(1) RUN(2) RUN(2) RUN(2) RUN(6) RUN(6) RUN(6) RUN(3) RUN(3) RUN(3) RUN(4) RUN(4) RUN(4) RUN(5) RUN(5) RUN(5) }
     (void)hipDeviceSynchronize();
-    unsigned long long h[10]; (void)hipMemcpy(h, d, 80, hipMemcpyDeviceToHost);
-    const char* n[5] = {"MFMAs only", "+ 8 ds_read_b128 per 32 MFMAs", "+ 4 LDS-DMA pieces per 32 MFMAs, vmcnt(16) + barrier per 64", "  ... without the barrier", "  ... pieces from a 256-KB region (L2 hits)"};
-    for (int v = 0; v < 5; ++v) printf("%-62s %.2f cycles per MFMA  %.1f per 128  clock %.3f GHz\n", n[v], (double)h[v * 2] / (iters * 64.0), (double)h[v * 2] / (iters * 64.0) * 128, (double)h[v * 2] / (double)h[v * 2 + 1] * 0.1);
+    unsigned long long h[14]; (void)hipMemcpy(h, d, 112, hipMemcpyDeviceToHost);
+    const char* n[7] = {"MFMAs only", "+ 8 ds_read_b128 per 32 MFMAs", "+ 4 LDS-DMA pieces per 32 MFMAs, vmcnt(16) + barrier per 64", "  ... without the barrier", "  ... pieces from a 256-KB region (L2 hits)", "  ... L2 hits, every piece 1 KB contiguous", "  ... from HBM, every piece 1 KB contiguous (with barrier)"};
+    for (int v = 0; v < 7; ++v) printf("%-62s %.2f cycles per MFMA  %.1f per 128  clock %.3f GHz\n", n[v], (double)h[v * 2] / (iters * 64.0), (double)h[v * 2] / (iters * 64.0) * 128, (double)h[v * 2] / (double)h[v * 2 + 1] * 0.1);
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
