@@ -130,6 +130,7 @@ struct Pending {
     int tail_pair = -1;            // index in scan_pairs of the last filtered launch of a staged MFMA search: timed by idx->tail_ev[seq & 3]
     uint32_t seq = 0;              // number of this search on its handle (n_begun when it was enqueued)
     bool early_sample = false;     // its sample pass was ordered in front of the previous search's last stage
+    uint32_t kp_boost_used = 1;    // the candidate-margin multiplier this search was enqueued with
     vrod_search_stats st{};
 
     // hipGraph replay of small, launch-bound searches (search_enqueue): the launches of a search
@@ -188,8 +189,9 @@ struct vrod_index {
     TailEv tail_ev[4];
     // Self-tuning candidate margin of the batched scan (search_enqueue_body / search_complete): k' = k + margin * kp_boost.
     // A failed certificate costs a band pass (one more scan of the corpus); doubling the margin costs a few per cent
-    // of hits.  kp_boost doubles (up to 4) after a search with failures, halves after 64 clean ones; failures AT 4 mean
+    // of hits.  kp_boost doubles (up to 8) after a search with failures, halves after 64 clean ones; failures AT 8 mean
     // the margin is not what those queries lack (exact duplicates): back to 1 and left alone for 256 searches.
+    static constexpr uint32_t kMaxKpBoost = 8;
     uint32_t kp_boost = 1, kp_clean = 0, kp_hold = 0;
     uint32_t n_begun = 0, n_ended = 0;   // searches enqueued / completed: slot = counter & 1
     hipEvent_t caller_ev = nullptr;      // orders the caller's stream before ours
@@ -596,6 +598,7 @@ static int search_enqueue_body(vrod_index* idx, Pending& P, const float* d_queri
         kp = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(N, kSelectChunk / 2), (uint64_t)k + (uint64_t)std::max<uint32_t>(16, k / 8) * idx->kp_boost);
     }
     st.kprime = kp;
+    P.kp_boost_used = idx->kp_boost;
     P.N = N; P.kp = kp;
     st.path = path;
     st.split_pass = split ? 1u : 0u;
@@ -1150,12 +1153,13 @@ static int search_complete(vrod_index* idx, Pending& P) {
         }
     }
     if (P.path == VROD_PATH_MFMA && !P.split && P.nq) {   // the margin follows what the certificates say (vrod_index::kp_boost)
+        // (two searches may be in flight: a verdict counts only for the multiplier the search itself ran with)
         if (idx->kp_hold) --idx->kp_hold;
         if (st.fallback_queries) {
             idx->kp_clean = 0;
-            if (idx->kp_boost >= 4) { idx->kp_boost = 1; idx->kp_hold = 256; }
-            else if (!idx->kp_hold) idx->kp_boost *= 2;
-        } else if (++idx->kp_clean >= 64 && idx->kp_boost > 1) {
+            if (P.kp_boost_used >= vrod_index::kMaxKpBoost) { idx->kp_boost = 1; idx->kp_hold = 256; }
+            else if (!idx->kp_hold && P.kp_boost_used == idx->kp_boost) idx->kp_boost *= 2;
+        } else if (P.kp_boost_used == idx->kp_boost && ++idx->kp_clean >= 64 && idx->kp_boost > 1) {
             idx->kp_boost /= 2;
             idx->kp_clean = 0;
         }
